@@ -1,0 +1,144 @@
+/*
+ * orc_oracle.h -- CPU ORACLE for the ORC stripe -> Arrow decode path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the algorithms of
+ * datafusion-contrib/orc-rust v0.8.0 (src/compression.rs, src/encoding/,
+ * src/array_decoder/), written from the reference's behaviour, streaming and
+ * single threaded like the reference.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product (orc_rust_amd/) never
+ * links, imports or calls anything in this directory.
+ *
+ * Parity pin: checked in tests/test_oracle_*.py against (a) every byte-level
+ * known-answer vector of the reference's own unit tests,
+ * (b) the reference's fixture files (tests/golden/data/) with expectations
+ * produced by PyArrow / Apache ORC C++ -- the same independent oracle the
+ * reference's integration suite is pinned to (scripts/generate_arrow.py:17-36)
+ * -- and (c) system zlib / pyarrow.Codec for the block codecs.
+ * The reference itself (Rust) cannot be built here: no cargo/rustc in the image.
+ */
+#ifndef ORC_ORACLE_H
+#define ORC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes: 1:1 with the OrcError variants the path raises (error.rs:31-174) */
+enum {
+  OO_OK = 0,
+  OO_IO_ERROR = 1,          /* IoError: short read / unexpected EOF            */
+  OO_OUT_OF_SPEC = 2,       /* OutOfSpec{msg}                                  */
+  OO_VARINT_TOO_LARGE = 3,  /* VarintTooLarge                                  */
+  OO_DECODE_TIMESTAMP = 4,  /* DecodeTimestamp{..}                             */
+  OO_OFFSET_OVERFLOW = 5,   /* OffsetOverflow{..}                              */
+  OO_MISMATCHED_SCHEMA = 6, /* MismatchedSchema                                */
+  OO_UNSUPPORTED = 7,       /* UnsupportedTypeVariant                          */
+  OO_ARROW = 8,             /* Arrow (UTF-8 / dictionary key / offsets)        */
+  OO_BUILD_DECODER = 9,     /* Build{Zstd,Snappy,Lz4}Decoder / inflate error   */
+  OO_UNEXPECTED = 10
+};
+
+/* proto CompressionKind (format/orc_proto.proto:383-390) */
+enum { OO_COMP_NONE = 0, OO_COMP_ZLIB = 1, OO_COMP_SNAPPY = 2, OO_COMP_LZO = 3, OO_COMP_LZ4 = 4, OO_COMP_ZSTD = 5 };
+
+/* ---- L0: block codecs (compression.rs:142-195) ---------------------------------------- */
+/* each returns the number of bytes written, or -1 on a malformed block / overflow of cap  */
+long oo_inflate_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+long oo_snappy_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+long oo_lz4_block(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+long oo_zstd_frame(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+
+/* compression.rs:113-123 : returns length, *is_original set */
+uint32_t oo_decode_chunk_header(const uint8_t b[3], int* is_original);
+
+/* Decompress a whole ORC stream (chunk framing + codec) into a malloc'd buffer.
+ * Returns status; *out / *out_len receive the plain bytes decoded BEFORE any error. */
+int oo_stream_decompress(const uint8_t* src, size_t n, int compression_kind, size_t block_size,
+                         uint8_t** out, size_t* out_len);
+void oo_free(void* p);
+
+/* ---- L1: value decoders (encoding/) -------------------------------------------------- */
+typedef struct oo_reader oo_reader; /* std::io::Read over a (possibly compressed) stream */
+oo_reader* oo_reader_new(const uint8_t* src, size_t n, int compression_kind, size_t block_size);
+void oo_reader_free(oo_reader* r);
+
+/* Integer RLE.  version 1|2, is_signed 0|1, nbits 16|32|64 (the NInt the reference decodes to). */
+typedef struct oo_int_rle oo_int_rle;
+oo_int_rle* oo_int_rle_new(oo_reader* r, int version, int is_signed, int nbits);
+int oo_int_rle_decode(oo_int_rle* d, int64_t* out, size_t n); /* PrimitiveValueDecoder::decode */
+void oo_int_rle_free(oo_int_rle* d);
+
+typedef struct oo_byte_rle oo_byte_rle;
+oo_byte_rle* oo_byte_rle_new(oo_reader* r);
+int oo_byte_rle_decode(oo_byte_rle* d, int8_t* out, size_t n);
+void oo_byte_rle_free(oo_byte_rle* d);
+
+typedef struct oo_bool_dec oo_bool_dec;
+oo_bool_dec* oo_bool_new(oo_reader* r);
+int oo_bool_decode(oo_bool_dec* d, uint8_t* out /* one byte per bool */, size_t n);
+void oo_bool_free(oo_bool_dec* d);
+
+/* zigzag varint -> i128 (encoding/decimal.rs:28-52); out = lo,hi pairs (little endian i128) */
+int oo_varint128_decode(oo_reader* r, uint64_t* out_lohi, size_t n);
+/* base-128 varint for N bits (util.rs:475-527) */
+int oo_read_varint(oo_reader* r, int nbits, int is_signed, int64_t* out);
+
+/* encoding/timestamp.rs:121-192.  unit: 0 s, 1 ms, 2 us, 3 ns */
+int oo_decode_timestamp(int64_t base, int64_t seconds, int64_t nanos, int unit, int64_t* out);
+/* array_decoder/decimal.rs:138-166 */
+void oo_fix_i128_scale(const uint64_t in_lohi[2], uint32_t fixed_scale, int32_t varying_scale, uint64_t out_lohi[2]);
+
+/* ---- L2: array decoders (array_decoder/) --------------------------------------------- */
+/* ORC type kinds (format/orc_proto.proto Type.Kind) */
+enum {
+  OO_T_BOOLEAN = 0, OO_T_BYTE = 1, OO_T_SHORT = 2, OO_T_INT = 3, OO_T_LONG = 4, OO_T_FLOAT = 5,
+  OO_T_DOUBLE = 6, OO_T_STRING = 7, OO_T_BINARY = 8, OO_T_TIMESTAMP = 9, OO_T_LIST = 10,
+  OO_T_MAP = 11, OO_T_STRUCT = 12, OO_T_UNION = 13, OO_T_DECIMAL = 14, OO_T_DATE = 15,
+  OO_T_VARCHAR = 16, OO_T_CHAR = 17, OO_T_TIMESTAMP_INSTANT = 18
+};
+/* Stream.Kind (orc_proto.proto:125-143) */
+enum { OO_S_PRESENT = 0, OO_S_DATA = 1, OO_S_LENGTH = 2, OO_S_DICTIONARY_DATA = 3, OO_S_SECONDARY = 5 };
+
+typedef struct {
+  int32_t kind; /* OO_S_* */
+  const uint8_t* ptr;
+  uint64_t len;
+} oo_stream_t;
+
+typedef struct {
+  int32_t orc_type;        /* OO_T_*                                                     */
+  int32_t encoding;        /* ColumnEncoding.Kind 0 DIRECT 1 DICTIONARY 2 DIRECT_V2 3 DICTIONARY_V2 */
+  uint32_t dictionary_size;
+  uint32_t precision, scale; /* Decimal                                                  */
+  int32_t ts_unit;         /* timestamp target unit 0 s 1 ms 2 us 3 ns                    */
+  int64_t ts_base;         /* seconds of the ORC epoch since the UNIX epoch for this stripe */
+  int32_t compression;     /* OO_COMP_*                                                   */
+  uint64_t block_size;
+  uint32_t n_streams;
+  const oo_stream_t* streams;
+} oo_column_desc;
+
+/* One decoded batch (array_decoder/mod.rs: next_batch).  All buffers are malloc'd by the
+ * oracle and stay valid until the next call on the same column / oo_column_free. */
+typedef struct {
+  int32_t status;        /* OO_*                                                          */
+  uint64_t length;       /* rows                                                          */
+  uint64_t null_count;
+  const uint8_t* validity; /* Arrow LSB bitmap, NULL when the batch has no nulls          */
+  const uint8_t* values;   /* fixed width values / Boolean bitmap / string bytes          */
+  uint64_t values_len;     /* bytes                                                       */
+  const int32_t* offsets;  /* length+1 i32 offsets for String/Binary, else NULL           */
+} oo_batch;
+
+typedef struct oo_column oo_column;
+oo_column* oo_column_new(const oo_column_desc* d, int* status);
+int oo_column_next_batch(oo_column* c, uint64_t batch_size, oo_batch* out);
+void oo_column_free(oo_column* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
