@@ -1,0 +1,178 @@
+/*
+ * orcgpu.h -- C ABI of the MI355X-native ORC stripe decoder (liborcgpu.so).
+ *
+ * Drop-in boundary.  In datafusion-contrib/orc-rust the stripe -> Arrow hot path sits behind a
+ * Rust trait-object seam, not an FFI:
+ *     NaiveStripeDecoder::new_with_selection(stripe, schema_ref, batch_size, row_selection)
+ *         src/array_decoder/mod.rs:570-594, installed at src/arrow_reader.rs:310-316
+ *     trait ArrayBatchDecoder::next_batch(batch_size, parent_present) -> ArrayRef
+ *         src/array_decoder/mod.rs:61-85, built by array_decoder_factory  :390-511
+ * The inputs at that seam are `Stripe { columns, stream_map: HashMap<(u32, Kind), Bytes>,
+ * compression, number_of_rows, tz }` (src/stripe.rs:119-125, :311-316).  This header is what a
+ * Rust shim implementing `Iterator<Item = Result<RecordBatch>>` binds instead of building the
+ * CPU decoders (see INTEGRATION.md for the `extern "C"` block and the arrow::ffi import).
+ *
+ * Everything below is plain C: pointers, sizes and POD structs; no C++/torch types.
+ * Threading: a context is thread-compatible (one thread at a time, may migrate), like
+ * `ArrayBatchDecoder: Send` (array_decoder/mod.rs:61).  One HIP stream per context.
+ */
+#ifndef ORCGPU_H
+#define ORCGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: 1:1 with the OrcError variants the path raises (src/error.rs:31-174) ---- */
+enum {
+  ORCGPU_OK = 0,
+  ORCGPU_IO_ERROR = 1,          /* IoError (short read / unexpected end of stream)          */
+  ORCGPU_OUT_OF_SPEC = 2,       /* OutOfSpec { msg }                                        */
+  ORCGPU_VARINT_TOO_LARGE = 3,  /* VarintTooLarge                                           */
+  ORCGPU_DECODE_TIMESTAMP = 4,  /* DecodeTimestamp { seconds, nanoseconds, to_time_unit }   */
+  ORCGPU_OFFSET_OVERFLOW = 5,   /* OffsetOverflow { total_length, max_size, batch_size }    */
+  ORCGPU_MISMATCHED_SCHEMA = 6, /* MismatchedSchema { orc_type, arrow_type }                */
+  ORCGPU_UNSUPPORTED = 7,       /* UnsupportedTypeVariant { msg }                           */
+  ORCGPU_ARROW = 8,             /* Arrow (UTF-8 validation, dictionary key, offsets)        */
+  ORCGPU_BUILD_DECODER = 9,     /* Build{Zstd,Snappy,Lz4}Decoder / inflate failure          */
+  ORCGPU_UNEXPECTED = 10,       /* Unexpected { msg }                                       */
+  ORCGPU_HIP_ERROR = 100,       /* HIP runtime failure (no device, out of memory, ...)      */
+  ORCGPU_INVALID_ARGUMENT = 101
+};
+
+/* proto CompressionKind (format/orc_proto.proto:383-390) */
+enum { ORCGPU_COMP_NONE = 0, ORCGPU_COMP_ZLIB = 1, ORCGPU_COMP_SNAPPY = 2, ORCGPU_COMP_LZO = 3, ORCGPU_COMP_LZ4 = 4, ORCGPU_COMP_ZSTD = 5 };
+
+/* proto Type.Kind (format/orc_proto.proto:199-228; src/schema.rs:241-320) */
+enum {
+  ORCGPU_T_BOOLEAN = 0, ORCGPU_T_BYTE = 1, ORCGPU_T_SHORT = 2, ORCGPU_T_INT = 3, ORCGPU_T_LONG = 4, ORCGPU_T_FLOAT = 5,
+  ORCGPU_T_DOUBLE = 6, ORCGPU_T_STRING = 7, ORCGPU_T_BINARY = 8, ORCGPU_T_TIMESTAMP = 9, ORCGPU_T_LIST = 10,
+  ORCGPU_T_MAP = 11, ORCGPU_T_STRUCT = 12, ORCGPU_T_UNION = 13, ORCGPU_T_DECIMAL = 14, ORCGPU_T_DATE = 15,
+  ORCGPU_T_VARCHAR = 16, ORCGPU_T_CHAR = 17, ORCGPU_T_TIMESTAMP_INSTANT = 18
+};
+
+/* proto Stream.Kind (format/orc_proto.proto:125-143) */
+enum { ORCGPU_S_PRESENT = 0, ORCGPU_S_DATA = 1, ORCGPU_S_LENGTH = 2, ORCGPU_S_DICTIONARY_DATA = 3, ORCGPU_S_DICTIONARY_COUNT = 4,
+       ORCGPU_S_SECONDARY = 5, ORCGPU_S_ROW_INDEX = 6, ORCGPU_S_BLOOM_FILTER = 7, ORCGPU_S_BLOOM_FILTER_UTF8 = 8 };
+
+/* proto ColumnEncoding.Kind (format/orc_proto.proto:150-155; src/column.rs:47-59) */
+enum { ORCGPU_ENC_DIRECT = 0, ORCGPU_ENC_DICTIONARY = 1, ORCGPU_ENC_DIRECT_V2 = 2, ORCGPU_ENC_DICTIONARY_V2 = 3 };
+
+/* Arrow target of a column = the `hinted_arrow_type` of array_decoder_factory (mod.rs:390-394).
+ * 0 picks the default mapping of src/schema.rs:503-579. */
+enum {
+  ORCGPU_ARROW_DEFAULT = 0,
+  ORCGPU_ARROW_TIMESTAMP_S = 1, ORCGPU_ARROW_TIMESTAMP_MS = 2, ORCGPU_ARROW_TIMESTAMP_US = 3, ORCGPU_ARROW_TIMESTAMP_NS = 4
+};
+
+typedef struct orcgpu_ctx orcgpu_ctx;          /* one GPU, one HIP stream, reusable workspace */
+typedef struct orcgpu_staged orcgpu_staged;    /* stripe streams resident in HBM              */
+typedef struct orcgpu_result orcgpu_result;    /* decoded Arrow buffers resident in HBM       */
+
+typedef struct {
+  uint64_t workspace_bytes;  /* initial HBM workspace (0 = grow on demand)  */
+  uint32_t flags;            /* reserved, 0                                 */
+} orcgpu_opts;
+
+/* One entry of Stripe.stream_map (src/stripe.rs:311-316): raw, possibly compressed bytes. */
+typedef struct {
+  uint32_t column_id;
+  int32_t kind;        /* ORCGPU_S_* */
+  const uint8_t* ptr;  /* HOST pointer (pageable or pinned) */
+  uint64_t len;
+} orcgpu_stream;
+
+/* One projected leaf column: what Column / DataType / ColumnEncoding carry (src/column.rs:24-59). */
+typedef struct {
+  uint32_t column_id;
+  int32_t orc_type;          /* ORCGPU_T_*                                   */
+  int32_t encoding;          /* ORCGPU_ENC_*  (rle version = column.rs:52-59) */
+  uint32_t dictionary_size;  /* column.rs:40-45                              */
+  uint32_t precision, scale; /* DECIMAL                                      */
+  int32_t arrow_target;      /* ORCGPU_ARROW_*                               */
+} orcgpu_column;
+
+typedef struct {
+  uint64_t n_rows;           /* Stripe.number_of_rows                                              */
+  int32_t compression;       /* ORCGPU_COMP_* (Compression::from_proto, src/compression.rs:52-83)  */
+  uint64_t block_size;       /* max_decompressed_block_size, 0 = 262144 (compression.rs:31)        */
+  int64_t ts_base_seconds;   /* ORC epoch in the writer timezone (array_decoder/timestamp.rs:133-147); 0 = 1420070400 */
+  uint32_t batch_size;       /* rows per RecordBatch, 0 = 8192 (arrow_reader.rs:37)                */
+  uint32_t n_streams;
+  const orcgpu_stream* streams;
+  uint32_t n_columns;
+  const orcgpu_column* columns;
+} orcgpu_stripe_desc;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+/* Returns NULL on failure (no HIP device: the library never falls back to a CPU path). */
+orcgpu_ctx* orcgpu_open(int device, const orcgpu_opts* opts);
+void orcgpu_close(orcgpu_ctx* ctx);
+const char* orcgpu_last_error(const orcgpu_ctx* ctx);
+const char* orcgpu_version(void);
+
+/* ---- staging: host stream bytes -> HBM --------------------------------------------------------- */
+/* Copies every stream of the stripe into one HBM arena through a pinned bounce buffer
+ * (hipMemcpyAsync) and scans the 3-byte chunk headers (compression.rs:113-123, :244-267) on the
+ * host while the bytes are at hand.  The returned handle keeps its own copy of the descriptor. */
+int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* desc, orcgpu_staged** out);
+void orcgpu_staged_free(orcgpu_staged* s);
+uint64_t orcgpu_staged_bytes(const orcgpu_staged* s); /* sum of Stream.length staged in HBM */
+
+/* ---- decode: staged stripes -> Arrow buffers in HBM -------------------------------------------- */
+/* Decodes n staged stripes with shared kernel launches.  Device work only; ends with ONE small
+ * device-to-host copy (error words, null counts, string byte totals).  results[i] is allocated
+ * unless it is passed non-NULL from an earlier decode of a same-shaped stripe (buffer reuse). */
+int orcgpu_decode_staged(orcgpu_ctx* ctx, orcgpu_staged* const* stripes, uint32_t n, orcgpu_result** results);
+/* Convenience: stage + decode one stripe. */
+int orcgpu_stripe_decode(orcgpu_ctx* ctx, const orcgpu_stripe_desc* desc, orcgpu_result** out);
+void orcgpu_result_free(orcgpu_result* r);
+
+/* ---- result inspection ------------------------------------------------------------------------- */
+/* Decode status of the stripe: ORCGPU_OK, or the error of the FIRST failing batch; *batch gets the
+ * index of that batch (batches before it are valid, as with the reference's iterator, which
+ * yields Ok batches until the failing one: arrow_reader.rs:333-346). */
+int orcgpu_result_status(const orcgpu_result* r, uint32_t* batch, uint32_t* column);
+uint64_t orcgpu_result_rows(const orcgpu_result* r);
+uint32_t orcgpu_result_batches(const orcgpu_result* r);
+uint64_t orcgpu_result_arrow_bytes(const orcgpu_result* r); /* value + offset + validity bytes emitted */
+
+/* Raw view of one column of one batch.  Pointers are DEVICE pointers unless copied with
+ * orcgpu_result_copy_batch; layouts follow the Arrow columnar format:
+ *   values    fixed width data / Boolean bitmap (LSB first) / string bytes of this batch
+ *   offsets   length+1 int32, first = 0 (restart per batch, array_decoder/string.rs:139-140)
+ *   validity  LSB-first bitmap, NULL when null_count == 0 (array_decoder/mod.rs:247-251) */
+typedef struct {
+  uint64_t length;
+  uint64_t null_count;
+  const void* validity;
+  const void* values;
+  uint64_t values_bytes;
+  const int32_t* offsets;
+} orcgpu_batch_view;
+int orcgpu_result_batch_view(const orcgpu_result* r, uint32_t batch, uint32_t column, orcgpu_batch_view* out);
+/* Copies one column-batch to host memory supplied by the caller (sizes from the view). */
+int orcgpu_result_copy_batch(orcgpu_ctx* ctx, const orcgpu_result* r, uint32_t batch, uint32_t column, void* values,
+                             int32_t* offsets, void* validity);
+
+/* ---- Arrow C Data Interface export (https://arrow.apache.org/docs/format/CDataInterface.html) ---- */
+struct ArrowSchema;
+struct ArrowArray;
+/* Exports batch `batch` as a struct array (one child per projected column) into HOST memory owned
+ * by the release callbacks; a Rust caller imports it with arrow::ffi::from_ffi, Python with
+ * pyarrow.RecordBatch._import_from_c.  Field names are "c<column_id>"; the caller renames. */
+int orcgpu_result_export_batch(orcgpu_ctx* ctx, const orcgpu_result* r, uint32_t batch, struct ArrowArray* out_array,
+                               struct ArrowSchema* out_schema);
+
+/* ---- timing hooks used by bench.py (HIP events on the context's own stream) ---------------------- */
+/* Milliseconds the device spent in the last orcgpu_decode_staged call, whole call and the RLE
+ * expansion kernels alone (the dominant kernel), measured with hipEvents on the ctx stream. */
+int orcgpu_last_timing(const orcgpu_ctx* ctx, float* total_ms, float* expand_ms, uint32_t* expand_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,243 @@
+"""ctypes binding of the C ABI in include/orcgpu.h (liborcgpu.so).
+
+This is plumbing only: every function here forwards to the HIP library.  There is no CPU
+fallback -- if the library is missing, or no MI355X is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+OK = 0
+ERR_NAMES = {
+    0: "Ok", 1: "IoError", 2: "OutOfSpec", 3: "VarintTooLarge", 4: "DecodeTimestamp", 5: "OffsetOverflow", 6: "MismatchedSchema",
+    7: "UnsupportedTypeVariant", 8: "Arrow", 9: "BuildDecoder", 10: "Unexpected", 100: "HipError", 101: "InvalidArgument",
+}
+COMP = {"none": 0, "zlib": 1, "snappy": 2, "lzo": 3, "lz4": 4, "zstd": 5}
+EXPORTS = [
+    "orcgpu_open", "orcgpu_close", "orcgpu_last_error", "orcgpu_version", "orcgpu_stage_stripe", "orcgpu_staged_free",
+    "orcgpu_staged_bytes", "orcgpu_decode_staged", "orcgpu_stripe_decode", "orcgpu_result_free", "orcgpu_result_status",
+    "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
+    "orcgpu_result_copy_batch", "orcgpu_result_export_batch", "orcgpu_last_timing",
+]
+
+
+class OrcGpuError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "?"), code, msg))
+        self.code = code
+
+
+class Stream(C.Structure):
+    _fields_ = [("column_id", C.c_uint32), ("kind", C.c_int32), ("ptr", C.c_void_p), ("len", C.c_uint64)]
+
+
+class Column(C.Structure):
+    _fields_ = [("column_id", C.c_uint32), ("orc_type", C.c_int32), ("encoding", C.c_int32), ("dictionary_size", C.c_uint32),
+                ("precision", C.c_uint32), ("scale", C.c_uint32), ("arrow_target", C.c_int32)]
+
+
+class StripeDesc(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("compression", C.c_int32), ("block_size", C.c_uint64), ("ts_base_seconds", C.c_int64),
+                ("batch_size", C.c_uint32), ("n_streams", C.c_uint32), ("streams", C.POINTER(Stream)), ("n_columns", C.c_uint32),
+                ("columns", C.POINTER(Column))]
+
+
+class BatchView(C.Structure):
+    _fields_ = [("length", C.c_uint64), ("null_count", C.c_uint64), ("validity", C.c_void_p), ("values", C.c_void_p),
+                ("values_bytes", C.c_uint64), ("offsets", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.SO
+
+
+def load():
+    """Loads liborcgpu.so (building it if the sources are newer).  Raises if it cannot be built or loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = _build.build()
+    L = C.CDLL(so)
+    L.orcgpu_open.restype = C.c_void_p
+    L.orcgpu_open.argtypes = [C.c_int, C.c_void_p]
+    L.orcgpu_close.argtypes = [C.c_void_p]
+    L.orcgpu_last_error.restype = C.c_char_p
+    L.orcgpu_last_error.argtypes = [C.c_void_p]
+    L.orcgpu_version.restype = C.c_char_p
+    L.orcgpu_stage_stripe.argtypes = [C.c_void_p, C.POINTER(StripeDesc), C.POINTER(C.c_void_p)]
+    L.orcgpu_staged_free.argtypes = [C.c_void_p]
+    L.orcgpu_staged_bytes.restype = C.c_uint64
+    L.orcgpu_staged_bytes.argtypes = [C.c_void_p]
+    L.orcgpu_decode_staged.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p)]
+    L.orcgpu_stripe_decode.argtypes = [C.c_void_p, C.POINTER(StripeDesc), C.POINTER(C.c_void_p)]
+    L.orcgpu_result_free.argtypes = [C.c_void_p]
+    L.orcgpu_result_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.orcgpu_result_rows.restype = C.c_uint64
+    L.orcgpu_result_rows.argtypes = [C.c_void_p]
+    L.orcgpu_result_batches.restype = C.c_uint32
+    L.orcgpu_result_batches.argtypes = [C.c_void_p]
+    L.orcgpu_result_arrow_bytes.restype = C.c_uint64
+    L.orcgpu_result_arrow_bytes.argtypes = [C.c_void_p]
+    L.orcgpu_result_batch_view.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(BatchView)]
+    L.orcgpu_result_copy_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orcgpu_result_export_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.orcgpu_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    _lib = L
+    return L
+
+
+class Context:
+    """orcgpu_ctx: one GPU, one HIP stream.  Raises when no HIP device is usable."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        self.h = self.L.orcgpu_open(device, None)
+        if not self.h:
+            raise OrcGpuError(100, "orcgpu_open(%d) failed: no usable HIP device (this library has no CPU path)" % device)
+
+    def close(self):
+        if self.h:
+            self.L.orcgpu_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def error(self):
+        return self.L.orcgpu_last_error(self.h).decode()
+
+    def _check(self, rc):
+        if rc:
+            raise OrcGpuError(rc, self.error())
+
+    def stage(self, n_rows, streams, columns, compression="none", block_size=262144, batch_size=8192, ts_base=0):
+        """streams: [(column_id, kind, bytes)], columns: [dict(column_id, orc_type, encoding, dictionary_size, precision, scale, arrow_target)]"""
+        keep = [bytes(b) if not isinstance(b, (bytes, np.ndarray)) else b for _, _, b in streams]
+        sarr = (Stream * max(1, len(streams)))()
+        for i, ((cid, kind, _), buf) in enumerate(zip(streams, keep)):
+            sarr[i].column_id = cid
+            sarr[i].kind = kind
+            if isinstance(buf, np.ndarray):
+                sarr[i].ptr = buf.ctypes.data
+                sarr[i].len = buf.nbytes
+            else:
+                sarr[i].ptr = C.cast(C.c_char_p(buf), C.c_void_p)
+                sarr[i].len = len(buf)
+        carr = (Column * max(1, len(columns)))()
+        for i, c in enumerate(columns):
+            carr[i].column_id = c["column_id"]
+            carr[i].orc_type = c["orc_type"]
+            carr[i].encoding = c.get("encoding", 2)
+            carr[i].dictionary_size = c.get("dictionary_size", 0)
+            carr[i].precision = c.get("precision", 0)
+            carr[i].scale = c.get("scale", 0)
+            carr[i].arrow_target = c.get("arrow_target", 0)
+        d = StripeDesc(n_rows, COMP[compression] if isinstance(compression, str) else compression, block_size, ts_base, batch_size,
+                       len(streams), sarr, len(columns), carr)
+        out = C.c_void_p()
+        self._check(self.L.orcgpu_stage_stripe(self.h, C.byref(d), C.byref(out)))
+        return Staged(self, out.value)
+
+    def decode(self, staged_list, results=None):
+        n = len(staged_list)
+        sarr = (C.c_void_p * n)(*[s.h for s in staged_list])
+        rarr = (C.c_void_p * n)(*[(r.h if r is not None else None) for r in (results or [None] * n)])
+        self._check(self.L.orcgpu_decode_staged(self.h, sarr, n, rarr))
+        if results:
+            return results
+        return [Result(self, rarr[i]) for i in range(n)]
+
+    def timing(self):
+        a, b, c = C.c_float(), C.c_float(), C.c_uint32()
+        self.L.orcgpu_last_timing(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+
+class Staged:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def nbytes(self):
+        return self.ctx.L.orcgpu_staged_bytes(self.h)
+
+    def free(self):
+        if self.h:
+            self.ctx.L.orcgpu_staged_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Result:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def free(self):
+        if self.h:
+            self.ctx.L.orcgpu_result_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def status(self):
+        b, c = C.c_uint32(), C.c_uint32()
+        st = self.ctx.L.orcgpu_result_status(self.h, C.byref(b), C.byref(c))
+        return st, b.value, c.value
+
+    @property
+    def rows(self):
+        return self.ctx.L.orcgpu_result_rows(self.h)
+
+    @property
+    def n_batches(self):
+        return self.ctx.L.orcgpu_result_batches(self.h)
+
+    @property
+    def arrow_bytes(self):
+        return self.ctx.L.orcgpu_result_arrow_bytes(self.h)
+
+    def view(self, batch, column):
+        v = BatchView()
+        self.ctx._check(self.ctx.L.orcgpu_result_batch_view(self.h, batch, column, C.byref(v)))
+        return v
+
+    def batch(self, batch, column):
+        """Host copy of one column-batch: dict(length, null_count, validity, values, offsets) -- the same
+        layout the CPU oracle reports, so parity tests compare bytes."""
+        v = self.view(batch, column)
+        n = v.length
+        values = np.zeros(max(1, v.values_bytes), dtype=np.uint8)
+        offsets = np.zeros(n + 1, dtype=np.int32) if v.offsets else None
+        validity = np.zeros((n + 7) // 8, dtype=np.uint8) if v.validity else None
+        self.ctx._check(self.ctx.L.orcgpu_result_copy_batch(
+            self.ctx.h, self.h, batch, column, values.ctypes.data, offsets.ctypes.data if offsets is not None else None,
+            validity.ctypes.data if validity is not None else None))
+        return {"status": 0, "length": n, "null_count": v.null_count, "validity": validity.tobytes() if validity is not None else None,
+                "values": values[:v.values_bytes].tobytes(), "offsets": offsets}
+
+    def export_batch(self, batch):
+        """Arrow C Data Interface export -> pyarrow.RecordBatch (zero-copy import of host buffers)."""
+        import pyarrow as pa
+        from pyarrow.cffi import ffi
+        a = ffi.new("struct ArrowArray*")
+        s = ffi.new("struct ArrowSchema*")
+        pa_ptr, ps_ptr = int(ffi.cast("uintptr_t", a)), int(ffi.cast("uintptr_t", s))
+        self.ctx._check(self.ctx.L.orcgpu_result_export_batch(self.ctx.h, self.h, batch, pa_ptr, ps_ptr))
+        return pa.RecordBatch._import_from_c(pa_ptr, ps_ptr)

@@ -1,0 +1,222 @@
+// column_kernels.hip -- PRESENT -> Arrow validity, null spacing and the per-type finishers.
+//
+//   PresentDecoder / BooleanDecoder bits are MSB-first (boolean.rs:48-54, :101-113); Arrow
+//   validity is LSB-first, omitted per batch when the batch has no nulls (array_decoder/mod.rs:247-251).
+//   decode_spaced leaves null slots at the caller's zero fill (encoding/mod.rs:64-91).
+//   Timestamp combine: encoding/timestamp.rs:121-192.  Decimal scale repair: array_decoder/decimal.rs:138-166.
+#include "rle_parse.h"
+
+struct ErrSlot {
+  unsigned long long v;  // min over (row or value index << 8 | code)
+};
+
+__device__ __forceinline__ void report_row(unsigned long long* err, uint64_t idx, uint32_t code) {
+  atomicMin(err, ((unsigned long long)idx << 8) | code);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PRESENT bytes (MSB-first) -> stripe-wide LSB-first bitmap words + per-word popcount.
+// One thread per 64 rows.  `avail_bytes` = scalars[total_idx] of the PRESENT byte-RLE job: rows
+// beyond the decoded bytes are treated as valid (the reference swallows a PRESENT decode error
+// and decodes the batch as if there were no PRESENT stream: derive_present_vec, mod.rs:247-251).
+extern "C" __global__ void __launch_bounds__(256) present_words_kernel(const uint8_t* pbytes, uint64_t n_rows, unsigned long long* vbits,
+                                                                        uint32_t* wpop, uint64_t n_words) {
+  uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  uint64_t x = ld_u64(pbytes + w * 8);
+  // reverse the bits inside each byte: bitreverse64 reverses everything, bswap restores byte order
+  unsigned long long v = __builtin_bswap64(__builtin_bitreverse64(x));
+  uint64_t rows_here = n_rows - w * 64;
+  if (rows_here < 64) v &= (1ull << rows_here) - 1;
+  vbits[w] = v;
+  wpop[w] = (uint32_t)__builtin_popcountll(v);
+}
+
+// Generic 2-level exclusive scan of u32 counts (tile = 1024 entries / workgroup).
+extern "C" __global__ void __launch_bounds__(256) scan_tiles_kernel(const uint32_t* in, uint32_t* out, uint32_t* tile_sum, uint64_t n) {
+  __shared__ uint32_t wsum[4];
+  uint64_t base = (uint64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+  uint32_t v[4];
+  for (int k = 0; k < 4; k++) v[k] = base + k < n ? in[base + k] : 0;
+  uint32_t s = v[0] + v[1] + v[2] + v[3];
+  uint32_t incl = s;
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(incl, o);
+    if ((int)(threadIdx.x & 63) >= o) incl += t;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += wsum[w];
+  uint32_t e = wbase + incl - s;
+  for (int k = 0; k < 4; k++) {
+    if (base + k < n) out[base + k] = e;
+    e += v[k];
+  }
+  if (threadIdx.x == 255) tile_sum[blockIdx.x] = e;
+}
+// single workgroup: exclusive scan of tile sums in place; total -> *total_out (u64)
+extern "C" __global__ void __launch_bounds__(256) scan_sums_kernel(uint32_t* tile_sum, uint64_t ntiles, uint64_t* total_out) {
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint64_t s = 0; s < ntiles; s += 256) {
+    uint64_t i = s + threadIdx.x;
+    uint64_t v = i < ntiles ? tile_sum[i] : 0;
+    uint64_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint64_t t = __shfl_up(incl, o);
+      if ((int)(threadIdx.x & 63) >= o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t wbase = carry_s;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += wsum[w];
+    if (i < ntiles) tile_sum[i] = (uint32_t)(wbase + incl - v);
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = wbase + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+extern "C" __global__ void __launch_bounds__(256) scan_apply_kernel(uint32_t* out, const uint32_t* tile_sum, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] += tile_sum[i >> 10];
+}
+
+// Per-batch validity bitmaps + null counts.  One thread per output word of a batch.
+// out layout: batch b at word offset b * words_per_batch.
+extern "C" __global__ void __launch_bounds__(256) validity_batches_kernel(const unsigned long long* vbits, uint64_t n_rows, uint32_t batch,
+                                                                           uint32_t words_per_batch, unsigned long long* out,
+                                                                           unsigned long long* null_counts, uint64_t n_out_words) {
+  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_out_words) return;
+  uint64_t b = t / words_per_batch, w = t % words_per_batch;
+  uint64_t row0 = b * batch + w * 64;
+  uint64_t bend = (b + 1) * (uint64_t)batch;
+  if (bend > n_rows) bend = n_rows;
+  unsigned long long v = 0;
+  uint32_t rows = 0;
+  if (row0 < bend) {
+    rows = bend - row0 < 64 ? (uint32_t)(bend - row0) : 64;
+    uint64_t sw = row0 >> 6;
+    uint32_t sh = row0 & 63;
+    unsigned long long lo = vbits[sw];
+    unsigned long long hi = (sh && ((sw + 1) * 64 < n_rows)) ? vbits[sw + 1] : 0;
+    v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    if (rows < 64) v &= (1ull << rows) - 1;
+    uint32_t nulls = rows - (uint32_t)__builtin_popcountll(v);
+    if (nulls) atomicAdd(&null_counts[b], (unsigned long long)nulls);
+  }
+  out[t] = v;
+}
+
+// Null spacing for fixed-width values: out[i] = valid(i) ? dense[rank(i)] : 0   (encoding/mod.rs:64-91)
+template <typename T>
+__device__ __forceinline__ void space_body(const T* dense, const unsigned long long* vbits, const uint32_t* rank, T* out, uint64_t n_rows) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  unsigned long long word = vbits[i >> 6];
+  uint32_t bit = i & 63;
+  T v = T(0);
+  if ((word >> bit) & 1) v = dense[(uint64_t)rank[i >> 6] + __builtin_popcountll(word & ((1ull << bit) - 1))];
+  out[i] = v;
+}
+extern "C" __global__ void __launch_bounds__(256) space8_kernel(const int8_t* d, const unsigned long long* vb, const uint32_t* rk, int8_t* o, uint64_t n) { space_body(d, vb, rk, o, n); }
+extern "C" __global__ void __launch_bounds__(256) space16_kernel(const int16_t* d, const unsigned long long* vb, const uint32_t* rk, int16_t* o, uint64_t n) { space_body(d, vb, rk, o, n); }
+extern "C" __global__ void __launch_bounds__(256) space32_kernel(const int32_t* d, const unsigned long long* vb, const uint32_t* rk, int32_t* o, uint64_t n) { space_body(d, vb, rk, o, n); }
+extern "C" __global__ void __launch_bounds__(256) space64_kernel(const int64_t* d, const unsigned long long* vb, const uint32_t* rk, int64_t* o, uint64_t n) { space_body(d, vb, rk, o, n); }
+
+// Float/Double without nulls: plain copy of the raw little-endian stream (float.rs:70-74).
+extern "C" __global__ void __launch_bounds__(256) copy_bytes_kernel(const uint8_t* src, uint8_t* dst, uint64_t n) {
+  uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  if (i + 16 <= n) {
+    uint4 v;
+    __builtin_memcpy(&v, src + i, 16);
+    *reinterpret_cast<uint4*>(dst + i) = v;
+  } else {
+    for (uint64_t k = i; k < n; k++) dst[k] = src[k];
+  }
+}
+
+// Boolean DATA: dense MSB-first bit bytes -> per-batch LSB-first value bitmaps (BooleanArrayDecoder,
+// array_decoder/mod.rs:163-183).  One thread per output word; with nulls the dense bits are
+// deposited into the valid positions.
+extern "C" __global__ void __launch_bounds__(256) bool_values_kernel(const uint8_t* dbytes, const unsigned long long* vbits, const uint32_t* rank,
+                                                                      uint64_t n_rows, uint32_t batch, uint32_t words_per_batch,
+                                                                      unsigned long long* out, uint64_t n_out_words) {
+  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_out_words) return;
+  uint64_t b = t / words_per_batch, w = t % words_per_batch;
+  uint64_t row0 = b * batch + w * 64;
+  uint64_t bend = (b + 1) * (uint64_t)batch;
+  if (bend > n_rows) bend = n_rows;
+  unsigned long long v = 0;
+  if (row0 < bend) {
+    uint32_t rows = bend - row0 < 64 ? (uint32_t)(bend - row0) : 64;
+    for (uint32_t k = 0; k < rows; k++) {
+      uint64_t row = row0 + k;
+      uint64_t d = row;
+      bool valid = true;
+      if (vbits) {
+        unsigned long long word = vbits[row >> 6];
+        uint32_t bit = row & 63;
+        valid = (word >> bit) & 1;
+        d = (uint64_t)rank[row >> 6] + __builtin_popcountll(word & ((1ull << bit) - 1));
+      }
+      if (valid && ((dbytes[d >> 3] >> (7 - (d & 7))) & 1)) v |= 1ull << k;
+    }
+  }
+  out[t] = v;
+}
+
+// Timestamp combine (encoding/timestamp.rs:121-192) fused with null spacing.
+// unit: 0 s, 1 ms, 2 us, 3 ns.
+extern "C" __global__ void __launch_bounds__(256) timestamp_kernel(const int64_t* secs, const int64_t* nanos, const unsigned long long* vbits,
+                                                                    const uint32_t* rank, int64_t* out, uint64_t n_rows, int64_t base,
+                                                                    int unit, unsigned long long* err) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  uint64_t d = i;
+  bool valid = true;
+  if (vbits) {
+    unsigned long long word = vbits[i >> 6];
+    uint32_t bit = i & 63;
+    valid = (word >> bit) & 1;
+    d = (uint64_t)rank[i >> 6] + __builtin_popcountll(word & ((1ull << bit) - 1));
+  }
+  int64_t r = 0;
+  if (valid) {
+    uint64_t nn = (uint64_t)nanos[d];
+    uint32_t zeros = nn & 7;
+    nn >>= 3;
+    if (zeros) {
+      uint64_t p = 10;
+      for (uint32_t k = 0; k < zeros; k++) p *= 10;
+      nn *= p;  // wrapping, as the release build of the reference
+    }
+    int64_t sse = (int64_t)((uint64_t)secs[d] + (uint64_t)base);
+    int64_t s = (sse < 0 && nn > 999999) ? sse - 1 : sse;
+    __int128 ns = (__int128)s * 1000000000 + (__int128)nn;
+    const int64_t per = unit == 0 ? 1000000000 : (unit == 1 ? 1000000 : (unit == 2 ? 1000 : 1));
+    __int128 q = ns / per;
+    bool bad = (ns % per) != 0 || q > (__int128)INT64_MAX || q < (__int128)INT64_MIN;
+    if (bad) report_row(err, i, ORC_E_TIMESTAMP);
+    r = (int64_t)q;
+  }
+  out[i] = r;
+}
+
+// scalars[dst] = ceil(scalars[src] / 8): bytes of a Boolean DATA bit stream needed for the non-null rows
+extern "C" __global__ void ceil_div8_kernel(uint64_t* scalars, uint32_t src, uint32_t dst) {
+  if (threadIdx.x == 0) scalars[dst] = (scalars[src] + 7) / 8;
+}
+
+// Float/Double: read_exact of `needed` values must fit in the stream (float.rs:70-74 -> IoError).
+extern "C" __global__ void float_check_kernel(const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx, uint32_t width, uint64_t* err) {
+  if (threadIdx.x == 0) {
+    uint64_t have = scalars[len_idx] / width;
+    if (have < scalars[needed_idx]) atomicMin((unsigned long long*)err, ((unsigned long long)have << 8) | ORC_E_IO);
+  }
+}

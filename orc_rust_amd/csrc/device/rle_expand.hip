@@ -1,0 +1,353 @@
+// rle_expand.hip -- pass 2 of the RLE decoders: cooperative run expansion, one wavefront per
+// group of `group_size` consecutive stream blocks.
+//
+// Replaces read_short_repeat_values / read_direct_values / read_patched_base /
+// read_delta_values (rle_v2/{short_repeat.rs:29-63, direct.rs:39-65, patched_base.rs:38-151,
+// delta.rs:44-116}), RLE v1 read_run / read_literals (rle_v1.rs:90-132) and byte RLE
+// (byte.rs:228-247), plus the copy-out of GenericRle::decode (rle.rs:68-107).
+//
+// Per iteration every lane that still has a run starting in ITS block parses that run's header
+// (up to 64 runs at once).  Random-access sub-encodings (SHORT_REPEAT, DIRECT, fixed DELTA, v1
+// runs, byte runs/literals) are then expanded value-parallel: a wave prefix sum over the run
+// lengths maps 64 consecutive output values per step onto lanes, whatever the run lengths, and
+// each lane bit-unpacks its value straight from the stream (HBM/L2, 8-byte unaligned load).
+// Sub-encodings with a dependency inside the run (varying DELTA: wave prefix sum of the deltas;
+// PATCHED_BASE: <=31-entry patch list resolved with a wave scan + LDS bitmap; v1 literal
+// varints: ballot on terminator bytes) are expanded run by run by the whole wave.
+// Values go to the dense output (one value per non-null row) with consecutive lanes writing
+// consecutive elements.  Overflow/width/EOF errors are recorded as
+// min(first value index of the failing run << 8 | code), which is exactly the batch in which
+// the reference's decode_batch would have failed.
+#include "rle_kernels.h"
+#include "rle_parse.h"
+
+struct WaveLds {
+  uint32_t start[65];
+  uint32_t meta[64];    // type | width << 8 | n << 16
+  uint32_t meta2[64];   // pw | pl << 8 | cw << 16
+  uint32_t oidx[64];    // output index of the run's first value
+  uint64_t pay[64];     // stream offset of the packed payload
+  uint64_t pay2[64];    // stream offset of the patch list
+  int64_t base[64];
+  int64_t delta[64];
+  unsigned long long bitmap[8];
+};
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(v, o);
+    if ((int)lane >= o) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, uint32_t lane) {
+  for (int o = 1; o < 64; o <<= 1) {
+    uint64_t t = __shfl_up(v, o);
+    if ((int)lane >= o) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ void store_val(void* out, uint32_t ob, uint64_t i, int64_t v) {
+  if (ob == 8) ((int64_t*)out)[i] = v;
+  else if (ob == 4) ((int32_t*)out)[i] = (int32_t)v;
+  else if (ob == 2) ((int16_t*)out)[i] = (int16_t)v;
+  else ((int8_t*)out)[i] = (int8_t)v;
+}
+
+__device__ __forceinline__ bool in_range_n(int64_t v, int nbits) { return trunc_n(v, nbits) == v; }
+// a + b == r (wrapping): did the signed addition overflow?
+__device__ __forceinline__ bool add_ovf(int64_t a, int64_t b, int64_t r) { return ((a ^ r) & (b ^ r)) < 0; }
+// a - b == r (wrapping): did the signed subtraction overflow?
+__device__ __forceinline__ bool sub_ovf(int64_t a, int64_t b, int64_t r) { return ((a ^ b) & (a ^ r)) < 0; }
+
+__device__ __forceinline__ void report(RleJob* j, uint64_t needed, uint64_t oi, uint32_t code) {
+  if (oi < needed) atomicMin(&j->err, ((unsigned long long)oi << 8) | code);
+}
+
+template <int CODEC>
+__device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, const uint64_t* scalars, uint32_t lg, WaveLds& L,
+                                             uint32_t lane) {
+  const uint8_t* data = j->data;
+  void* out = j->out;
+  const uint64_t len = scalars[j->len_idx];
+  const uint64_t needed = scalars[j->needed_idx];
+  const bool is_signed = j->is_signed;
+  const int nbits = j->nbits;
+  const uint32_t ob = j->out_bytes;
+  const uint32_t G = j->group_size;
+  const uint32_t eof_code = CODEC == CODEC_BYTE ? ORC_E_IO : ORC_E_OUT_OF_SPEC;
+
+  uint32_t lb = lg * G + lane;
+  bool active = false, tail_owner = false;
+  uint64_t pos = 0, end = 0;
+  uint64_t oi = 0;
+  if (lane < G && lb < j->nblocks && ((uint64_t)lb * RLE_BLK < len || lb == 0)) {
+    uint32_t b = j->block0 + lb;
+    uint32_t e = blk.entry[b];
+    uint64_t bend = (uint64_t)(lb + 1) * RLE_BLK;
+    end = bend < len ? bend : len;
+    pos = (uint64_t)lb * RLE_BLK + e;
+    oi = (uint64_t)blk.tile_base[b / RLE_TILE] + blk.voff[b];
+    active = e < RLE_BLK && pos < end && oi < needed;
+    tail_owner = (lb == 0 && len == 0) || (e < RLE_BLK && pos < end);
+  }
+  bool clean = true;  // no failing run seen by this lane
+
+  while (__ballot(active)) {
+    RunHdr h;
+    h.n = 0;
+    h.size = 0;
+    h.err = 0;
+    h.type = 0;
+    bool is_b2 = false;
+    uint32_t cnt = 0;
+    if (active) {
+      run_parse<CODEC, true>(data + pos, len - pos, is_signed, nbits, h);
+      if (h.err) {
+        report(j, needed, oi, h.err);
+        clean = false;
+      } else {
+        is_b2 = (h.type == RT_DELTA && h.width != 0) || h.type == RT_PATCHED || h.type == RT_V1_LIT;
+        cnt = is_b2 ? 0 : h.n;
+      }
+      L.meta[lane] = h.type | (h.width << 8) | (h.n << 16);
+      L.oidx[lane] = (uint32_t)oi;
+      L.pay[lane] = pos + h.payload;
+      L.base[lane] = h.base;
+      L.delta[lane] = h.delta;
+      if (CODEC == CODEC_RLE2 && h.type == RT_PATCHED) {
+        L.meta2[lane] = h.pw | (h.pl << 8) | (h.cw << 16);
+        L.pay2[lane] = pos + h.patch_off;
+      }
+    }
+    uint32_t incl = wave_incl_scan_u32(cnt, lane);
+    L.start[lane] = incl - cnt;
+    uint32_t T = __shfl(incl, 63);
+    if (lane == 63) L.start[64] = T;
+    wave_sync();
+
+    // ---- B1: value-parallel expansion of the random-access runs -----------------------------
+    for (uint32_t q0 = 0; q0 < T; q0 += 64) {
+      // run containing q0 (wave uniform)
+      uint32_t lo = 0, hi = 64;
+      while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (L.start[mid] <= q0) lo = mid;
+        else hi = mid;
+      }
+      uint32_t q = q0 + lane;
+      if (q < T) {
+        uint32_t r = lo;
+        if (q >= L.start[r + 1]) {
+          uint32_t l2 = r, h2 = 64;
+          while (h2 - l2 > 1) {
+            uint32_t mid = (l2 + h2) >> 1;
+            if (L.start[mid] <= q) l2 = mid;
+            else h2 = mid;
+          }
+          r = l2;
+        }
+        uint32_t idx = q - L.start[r];
+        uint32_t m = L.meta[r];
+        uint32_t type = m & 0xff, w = (m >> 8) & 0xff;
+        int64_t base = L.base[r];
+        uint64_t o0 = L.oidx[r];
+        int64_t v;
+        bool bad = false;
+        if (type == RT_SR || type == RT_B_RUN) {
+          v = base;
+        } else if (type == RT_DIRECT) {
+          uint64_t u = unpack_be(data + L.pay[r], idx, w);
+          v = is_signed ? zigzag_n(u, nbits) : trunc_n((int64_t)u, nbits);
+        } else if (type == RT_B_LIT) {
+          v = (int8_t)data[L.pay[r] + idx];
+        } else if (type == RT_DELTA) {  // fixed delta (delta.rs:84-93)
+          int64_t db = L.delta[r];
+          bool add = db > 0;
+          int64_t mag = db < 0 ? (int64_t)(0 - (uint64_t)db) : db;
+          uint64_t step = (uint64_t)idx * (uint64_t)mag;
+          v = add ? (int64_t)((uint64_t)base + step) : (int64_t)((uint64_t)base - step);
+          if (idx) {
+            int64_t prev = add ? (int64_t)((uint64_t)v - (uint64_t)mag) : (int64_t)((uint64_t)v + (uint64_t)mag);
+            bad = (add ? add_ovf(prev, mag, v) : sub_ovf(prev, mag, v)) || !in_range_n(v, nbits);
+          }
+        } else {  // RT_V1_RUN (rle_v1.rs:102-132): checked add/sub of |delta| in N
+          int64_t d = L.delta[r];
+          v = (int64_t)((uint64_t)base + (uint64_t)((int64_t)idx * d));
+          if (idx) {
+            int64_t prev = (int64_t)((uint64_t)v - (uint64_t)d);
+            bad = add_ovf(prev, d, v) || !in_range_n(v, nbits);
+          }
+        }
+        if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
+        uint64_t oo = o0 + idx;
+        if (oo < needed) store_val(out, ob, oo, v);
+      }
+    }
+
+    // ---- B2: runs with an internal dependency, one run at a time, whole wave ------------------
+    unsigned long long m2 = __ballot(active && is_b2);
+    while (m2) {
+      uint32_t r = (uint32_t)__builtin_ctzll(m2);
+      m2 &= m2 - 1;
+      uint32_t mt = L.meta[r];
+      uint32_t type = mt & 0xff, w = (mt >> 8) & 0xff, n = mt >> 16;
+      int64_t base = L.base[r];
+      uint64_t o0 = L.oidx[r];
+      const uint8_t* pp = data + L.pay[r];
+      bool bad = false;
+      if (CODEC == CODEC_RLE2 && type == RT_DELTA) {
+        // varying delta (delta.rs:94-113)
+        int64_t db = L.delta[r];
+        bool add = db > 0;
+        int64_t mag = db < 0 ? (int64_t)(0 - (uint64_t)db) : db;
+        int64_t v1 = add ? (int64_t)((uint64_t)base + (uint64_t)mag) : (int64_t)((uint64_t)base - (uint64_t)mag);
+        bad = (add ? add_ovf(base, mag, v1) : sub_ovf(base, mag, v1)) || !in_range_n(v1, nbits);
+        if (lane == 0 && o0 < needed) store_val(out, ob, o0, base);
+        if (lane == 1 && o0 + 1 < needed) store_val(out, ob, o0 + 1, v1);
+        int64_t acc = v1;
+        uint32_t nd = n - 2;
+        for (uint32_t c = 0; c < nd; c += 64) {
+          uint32_t i = c + lane;
+          bool valid = i < nd;
+          int64_t d = valid ? (int64_t)unpack_be(pp, i, w) : 0;
+          uint64_t s = wave_incl_scan_u64((uint64_t)d, lane);
+          int64_t v = add ? (int64_t)((uint64_t)acc + s) : (int64_t)((uint64_t)acc - s);
+          int64_t prev = add ? (int64_t)((uint64_t)v - (uint64_t)d) : (int64_t)((uint64_t)v + (uint64_t)d);
+          if (valid) {
+            bad |= (add ? add_ovf(prev, d, v) : sub_ovf(prev, d, v)) || !in_range_n(v, nbits);
+            uint64_t oo = o0 + 2 + i;
+            if (oo < needed) store_val(out, ob, oo, v);
+          }
+          acc = __shfl(v, 63);
+        }
+      } else if (CODEC == CODEC_RLE2 && type == RT_PATCHED) {
+        uint32_t m2v = L.meta2[r];
+        uint32_t pw = m2v & 0xff, pl = (m2v >> 8) & 0xff, cw = m2v >> 16;
+        const uint8_t* plist = data + L.pay2[r];
+        if (lane < 8) L.bitmap[lane] = 0;
+        wave_sync();
+        // patch list -> positions (patched_base.rs:93-143)
+        uint64_t e = lane < pl ? unpack_be(plist, lane, cw) : 0;
+        uint64_t gap = pw >= 64 ? 0 : (e >> pw);
+        uint64_t patch = pw >= 64 ? e : (e & ((1ull << pw) - 1));
+        bool cont = lane < pl && gap == 255 && patch == 0;
+        bool real = lane < pl && !cont;
+        uint64_t ppos = wave_incl_scan_u64(lane < pl ? gap : 0, lane);
+        // position of the previous real entry
+        unsigned long long realm = __ballot(real);
+        unsigned long long below = realm & ((1ull << lane) - 1);
+        int prev_real = below ? 63 - __builtin_clzll(below) : -1;
+        uint64_t prev_pos = __shfl(ppos, prev_real < 0 ? 0 : prev_real);
+        bool stuck = real && prev_real >= 0 && ppos == prev_pos;  // next gap 0: never matches again
+        bool beyond = real && ppos >= n;                           // not reached inside this run
+        unsigned long long stopm = __ballot(stuck || beyond);
+        uint32_t first_stop = stopm ? (uint32_t)__builtin_ctzll(stopm) : 64;
+        bool applied = real && lane < first_stop;
+        // a trailing continuation entry that the reference walks into indexes past the list (panic)
+        if (pl > 0) {
+          bool last_cont = __shfl((int)cont, pl - 1);
+          unsigned long long real_before = realm;  // all real entries precede a trailing continuation chain
+          int last_real = real_before ? 63 - __builtin_clzll(real_before) : -1;
+          if (last_cont && (last_real < 0 || (uint32_t)last_real < first_stop)) bad = true;
+        }
+        if (w >= 64 && __ballot(applied)) bad = true;  // checked_shl(value_bit_width)
+        if (applied) atomicOr(&L.bitmap[ppos >> 6], 1ull << (ppos & 63));
+        wave_sync();
+        for (uint32_t c = 0; c < n; c += 64) {
+          uint32_t i = c + lane;
+          if (i < n) {
+            bool patched = (L.bitmap[i >> 6] >> (i & 63)) & 1;
+            if (!patched) {
+              int64_t u = trunc_n((int64_t)unpack_be(pp, i, w), nbits);
+              int64_t v = (int64_t)((uint64_t)u + (uint64_t)base);
+              bad |= add_ovf(u, base, v) || !in_range_n(v, nbits);  // checked_add in N
+              uint64_t oo = o0 + i;
+              if (oo < needed) store_val(out, ob, oo, v);
+            }
+          }
+        }
+        if (applied && w < 64) {
+          int64_t u = trunc_n((int64_t)unpack_be(pp, (uint32_t)ppos, w), nbits);
+          int64_t pbits = trunc_n((int64_t)(patch << w), nbits);
+          int64_t v = trunc_n((int64_t)((uint64_t)(u | pbits) + (uint64_t)base), nbits);  // wrapping_add in N
+          uint64_t oo = o0 + ppos;
+          if (oo < needed) store_val(out, ob, oo, v);
+        }
+        wave_sync();
+      } else if (CODEC == CODEC_RLE1 && type == RT_V1_LIT) {
+        // n literal varints (rle_v1.rs:90-100): ballot on terminator bytes
+        uint64_t p0 = L.pay[r];
+        uint64_t vstart = p0;  // start of the varint that straddles into this 64-byte step
+        uint32_t done = 0;
+        for (uint64_t c = p0; done < n && c < len; c += 64) {
+          uint64_t bp = c + lane;
+          bool term = bp < len && !(data[bp] & 0x80);
+          unsigned long long tm = __ballot(term);
+          unsigned long long below = tm & ((1ull << lane) - 1);
+          uint32_t rank = done + (uint32_t)__builtin_popcountll(below);
+          if (term && rank < n) {
+            uint64_t s = below ? c + (63 - __builtin_clzll(below)) + 1 : vstart;
+            uint64_t u = 0;
+            uint32_t e = 0;
+            varint_n(data + s, len - s, nbits, &u, &e);
+            int64_t v = is_signed ? zigzag_n(u, nbits) : trunc_n((int64_t)u, nbits);
+            uint64_t oo = o0 + rank;
+            if (oo < needed) store_val(out, ob, oo, v);
+          }
+          if (tm) vstart = c + (63 - __builtin_clzll(tm)) + 1;
+          done += (uint32_t)__builtin_popcountll(tm);
+        }
+      }
+      if (__ballot(bad)) {
+        if (lane == 0) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
+      }
+    }
+    wave_sync();
+
+    if (active) {
+      pos += h.size;
+      oi += h.n;
+      active = pos < end && oi < needed;
+    }
+  }
+  // clean end of stream before `needed` values: "not enough values to decode"
+  if (tail_owner && clean && pos >= len) report(j, needed, oi, eof_code);
+}
+
+template <int CODEC>
+__device__ __forceinline__ void expand_entry(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars, uint32_t total_groups) {
+  __shared__ WaveLds lds[4];
+  uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t g = blockIdx.x * 4 + wv;
+  if (g >= total_groups) return;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].group0 <= g) lo = mid;
+    else hi = mid - 1;
+  }
+  RleJob* j = &jobs[lo];
+  uint32_t lg = g - j->group0;
+  if (lg >= j->ngroups) return;
+  expand_group<CODEC>(j, blk, scalars, lg, lds[wv], lane);
+}
+
+extern "C" __global__ void __launch_bounds__(256) rle2_expand_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
+                                                                      uint32_t total_groups) {
+  expand_entry<CODEC_RLE2>(jobs, njobs, blk, scalars, total_groups);
+}
+extern "C" __global__ void __launch_bounds__(256) rle1_expand_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
+                                                                      uint32_t total_groups) {
+  expand_entry<CODEC_RLE1>(jobs, njobs, blk, scalars, total_groups);
+}
+extern "C" __global__ void __launch_bounds__(256) byte_expand_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
+                                                                      uint32_t total_groups) {
+  expand_entry<CODEC_BYTE>(jobs, njobs, blk, scalars, total_groups);
+}

@@ -1,0 +1,36 @@
+// rle_kernels.h -- device data structures shared by the RLE kernels and the host planner.
+#pragma once
+#include <stdint.h>
+
+// A stream is cut into fixed blocks of RLE_BLK bytes.  One lane owns one block in the block
+// walk; one wavefront owns `group_size` consecutive blocks in the expansion.
+#define RLE_BLK 512u
+#define RLE_TILE 1024u          // blocks per scan tile; every job's block range is tile aligned
+#define RLE_NO_ERR 0xffffffffffffffffull
+
+struct RleJob {
+  const uint8_t* data;     // plain stream bytes in HBM (>= ORC_PAD bytes of slack behind them)
+  void* out;               // dense output, `out_bytes` per value
+  uint32_t len_idx;        // scalars[len_idx]    = stream length in bytes
+  uint32_t needed_idx;     // scalars[needed_idx] = number of values the column consumes
+  uint32_t total_idx;      // scalars[total_idx]  <- values present in the stream (written by the scan)
+  uint32_t block0;         // first global block (multiple of RLE_TILE)
+  uint32_t nblocks;        // upper bound of blocks (>= 1)
+  uint32_t group0;         // first global expansion group
+  uint32_t ngroups;
+  uint32_t group_size;     // blocks per wavefront in the expansion (1..64)
+  uint8_t codec;           // CODEC_*
+  uint8_t is_signed;
+  uint8_t nbits;           // width of the reference's NInt (8 for byte RLE)
+  uint8_t out_bytes;       // 1, 2, 4 or 8
+  uint32_t first_bad;      // first block whose entry disagrees with its predecessor (verify round)
+  unsigned long long err;  // min over (first value index of the failing run << 8 | ORC_E_*)
+};
+
+struct RleBlocks {
+  uint32_t* entry;      // offset of the first run header in the block (>= RLE_BLK: none), as used by the last walk
+  uint32_t* exit_;      // offset into the NEXT block of the first header after this block's runs
+  uint32_t* nvals;      // values produced by runs that START in the block
+  uint32_t* voff;       // exclusive prefix of nvals inside the block's scan tile
+  uint32_t* tile_base;  // per tile: values before the tile (within the job)
+};

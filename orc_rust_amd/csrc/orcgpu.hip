@@ -1,0 +1,478 @@
+// orcgpu.hip -- host side of liborcgpu.so: context, staging, per-stripe planning and kernel
+// launches behind the C ABI of include/orcgpu.h.
+//
+// The planner restates, for flat columns, what array_decoder_factory wires up per ORC type
+// (src/array_decoder/mod.rs:390-511; stream kinds per type: SURVEY.md Appendix C) and what
+// NaiveStripeDecoder iterates batch by batch (:513-564) -- except that a whole stripe (or
+// several) is decoded by a fixed sequence of kernel launches on one HIP stream:
+//
+//   H2D scalars/jobs -> [block decompress] -> RLE block walk (4 rounds + verify + repair)
+//   -> tile/job scans -> expand PRESENT -> validity/rank -> expand data streams -> finishers
+//   -> one D2H of the small summary (errors, null counts, string totals).
+//
+// There is NO CPU decode path in this library: every entry point that needs the GPU fails with
+// ORCGPU_HIP_ERROR when no HIP device is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orcgpu.h"
+#include "device/rle_kernels.h"
+#include "device/rle_parse.h"
+#include "device/rle_scan.hip"
+#include "device/rle_expand.hip"
+#include "device/column_kernels.hip"
+#include "device/string_kernels.hip"
+#include "device/decompress_kernels.hip"
+
+// Arrow C Data Interface structs (public, stable ABI)
+extern "C" {
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+}
+
+namespace {
+
+constexpr uint64_t kAlign = 256;
+constexpr int kWalkRounds = 4;
+inline uint64_t align_up(uint64_t v, uint64_t a = kAlign) { return (v + a - 1) / a * a; }
+
+struct DevBuf {
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t n) {
+    if (n <= cap) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + (1u << 20);
+    if (hipMalloc((void**)&p, want) != hipSuccess) {
+      if (hipMalloc((void**)&p, n) != hipSuccess) return false;
+      want = n;
+    }
+    cap = want;
+    return true;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct Bump {
+  uint64_t off = 0;
+  uint64_t take(uint64_t n, uint64_t a = kAlign) {
+    off = align_up(off, a);
+    uint64_t r = off;
+    off += n;
+    return r;
+  }
+};
+
+struct ChunkInfo {
+  uint64_t src_off;  // offset of the chunk payload inside the stream
+  uint32_t len;
+  uint32_t original;
+};
+
+struct StagedStream {
+  uint32_t column_id;
+  int32_t kind;
+  uint64_t off;  // offset inside the staged arena
+  uint64_t len;
+  std::vector<ChunkInfo> chunks;  // only for compressed stripes
+  bool framing_error = false;     // truncated chunk header / payload (compression.rs:253-261 panics)
+  uint64_t framed_len = 0;        // bytes covered by well-formed chunks
+};
+
+}  // namespace
+
+struct orcgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  DevBuf scratch;
+  uint8_t* pinned = nullptr;
+  size_t pinned_cap = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float last_total_ms = 0, last_expand_ms = 0;
+  uint32_t last_expand_launches = 0;
+  bool ensure_pinned(size_t n) {
+    if (n <= pinned_cap) return true;
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr;
+    pinned_cap = 0;
+    size_t want = n + n / 4 + (1u << 16);
+    if (hipHostMalloc((void**)&pinned, want, hipHostMallocDefault) != hipSuccess) return false;
+    pinned_cap = want;
+    return true;
+  }
+};
+
+struct orcgpu_staged {
+  orcgpu_ctx* ctx = nullptr;
+  orcgpu_stripe_desc desc{};
+  std::vector<orcgpu_column> cols;
+  std::vector<StagedStream> streams;
+  uint8_t* dev = nullptr;
+  size_t dev_bytes = 0;
+  uint64_t stream_bytes = 0;
+  const StagedStream* find(uint32_t col, int kind) const {
+    for (auto& s : streams)
+      if (s.column_id == col && s.kind == kind) return &s;
+    return nullptr;
+  }
+};
+
+namespace {
+
+// What one column contributes to a result
+struct ColumnOut {
+  int32_t orc_type = 0;
+  uint32_t column_id = 0;
+  uint32_t width = 0;        // fixed width in bytes (0 for strings / boolean)
+  bool is_string = false, is_bool = false;
+  int32_t ts_unit = 3;
+  uint32_t precision = 0, scale = 0;
+  bool has_present = false;
+  uint64_t values_off = 0, values_bytes = 0;      // in the result arena
+  uint64_t offsets_off = 0;                       // strings: n_batches * (B+1) int32
+  uint64_t validity_off = 0;                      // n_batches * words_per_batch u64
+  std::vector<uint64_t> null_counts;              // host copy, per batch
+  std::vector<uint64_t> char_base, char_total;    // strings: per batch, host copies
+  // error bookkeeping (resolved after the summary copy)
+  int status = 0;
+  uint32_t err_batch = 0;
+};
+
+}  // namespace
+
+struct orcgpu_result {
+  orcgpu_ctx* ctx = nullptr;
+  uint64_t n_rows = 0;
+  uint32_t batch = 8192, n_batches = 0, words_per_batch = 0;
+  DevBuf arena;
+  std::vector<ColumnOut> cols;
+  int status = 0;
+  uint32_t err_batch = 0, err_col = 0;
+  uint64_t arrow_bytes = 0;
+};
+
+namespace {
+
+void set_err(orcgpu_ctx* c, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+}
+
+#define HIP_TRY(ctx, expr)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      set_err(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return ORCGPU_HIP_ERROR;                                                          \
+    }                                                                                   \
+  } while (0)
+
+uint32_t type_width(int t) {
+  switch (t) {
+    case ORCGPU_T_BYTE: return 1;
+    case ORCGPU_T_SHORT: return 2;
+    case ORCGPU_T_INT:
+    case ORCGPU_T_DATE:
+    case ORCGPU_T_FLOAT: return 4;
+    case ORCGPU_T_LONG:
+    case ORCGPU_T_DOUBLE:
+    case ORCGPU_T_TIMESTAMP:
+    case ORCGPU_T_TIMESTAMP_INSTANT: return 8;
+    case ORCGPU_T_DECIMAL: return 16;
+    default: return 0;
+  }
+}
+bool is_string_type(int t) { return t == ORCGPU_T_STRING || t == ORCGPU_T_VARCHAR || t == ORCGPU_T_CHAR || t == ORCGPU_T_BINARY; }
+
+// ---- per-call plan ------------------------------------------------------------------------------
+enum JobClass { JC_PRESENT = 0, JC_RLE2 = 1, JC_RLE1 = 2, JC_BYTE = 3, JC_COUNT = 4 };
+
+struct JobPlan {
+  int cls;
+  uint8_t codec, is_signed, nbits, out_bytes;
+  const uint8_t* data;      // device pointer to the plain stream (may be assigned later)
+  uint64_t data_scratch_off = ~0ull;  // when the plain stream lives in scratch (decompressed)
+  uint64_t len_upper;       // upper bound of the plain length
+  uint32_t len_idx, needed_idx, total_idx;
+  uint64_t out_scratch_off = ~0ull;   // dense output in scratch ...
+  uint64_t out_result_off = ~0ull;    // ... or directly in the result arena
+  int result_index = 0;
+  uint64_t expect_values;   // host estimate of values (for group sizing)
+  // filled while laying out
+  uint32_t block0 = 0, nblocks = 0, group0 = 0, ngroups = 0, group_size = 64;
+  int stripe = 0, col = 0, role = 0;  // role: stream kind the job decodes
+  int final_index = -1;
+};
+
+struct PlainStream {
+  const uint8_t* dev = nullptr;  // device pointer when uncompressed (inside the staged arena)
+  uint64_t scratch_off = ~0ull;  // scratch offset when decompressed
+  uint64_t len_upper = 0;
+  uint32_t len_idx = 0;          // scalar holding the actual plain length
+  bool exists = false;
+};
+
+struct ColPlan {
+  int stripe, col;
+  orcgpu_column c;
+  uint64_t n_rows;
+  bool has_present = false;
+  PlainStream present, data, length, secondary, dict;
+  // scratch
+  uint64_t pbytes_off = 0, vbits_off = 0, wpop_off = 0, rank_off = 0, rank_tiles_off = 0;
+  uint64_t n_words = 0, n_rank_tiles = 0;
+  uint32_t nonnull_idx = 0;   // scalar: number of non-null rows (= needed of the data streams)
+  uint32_t nullcount_off = 0; // index into the summary null-count array (per batch)
+  uint32_t err_idx = 0;       // scalar: finisher error word
+  int job_present = -1, job_data = -1, job_length = -1, job_secondary = -1;
+  uint64_t dense_off = 0, dense2_off = 0;  // dense temporaries in scratch
+  // strings
+  uint64_t lens_off = 0;       // spaced int32 lengths per row (scratch)
+  uint32_t chartot_off = 0;    // index into the summary per-batch char totals
+  uint64_t dictoff_off = 0;    // dictionary offsets (scratch, int32[dict+1])
+  uint32_t dictbytes_idx = 0;
+};
+
+struct Plan {
+  std::vector<orcgpu_staged*> stripes;
+  std::vector<orcgpu_result*> results;
+  std::vector<ColPlan> cols;
+  std::vector<JobPlan> jobs;
+  std::vector<uint64_t> scalars;
+  Bump scratch;
+  std::vector<Bump> result_bump;
+  uint64_t n_nullcount_slots = 0, n_chartot_slots = 0;
+  uint32_t new_scalar(uint64_t v) {
+    scalars.push_back(v);
+    return (uint32_t)scalars.size() - 1;
+  }
+};
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* orcgpu_version(void) { return "orcgpu 0.1 (gfx950)"; }
+
+orcgpu_ctx* orcgpu_open(int device, const orcgpu_opts* opts) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  orcgpu_ctx* c = new orcgpu_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  for (auto& e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      delete c;
+      return nullptr;
+    }
+  if (opts && opts->workspace_bytes) c->scratch.ensure(opts->workspace_bytes);
+  return c;
+}
+
+void orcgpu_close(orcgpu_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->scratch.release();
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  for (auto& e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* orcgpu_last_error(const orcgpu_ctx* c) { return c ? c->err.c_str() : "no context (no usable HIP device)"; }
+
+// ---- staging --------------------------------------------------------------------------------------
+int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_staged** out) {
+  if (!ctx || !d || !out) return ORCGPU_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  orcgpu_staged* s = new orcgpu_staged();
+  s->ctx = ctx;
+  s->desc = *d;
+  if (!s->desc.block_size) s->desc.block_size = 262144;
+  if (!s->desc.batch_size) s->desc.batch_size = 8192;
+  if (!s->desc.ts_base_seconds) s->desc.ts_base_seconds = 1420070400;
+  s->cols.assign(d->columns, d->columns + d->n_columns);
+  s->desc.columns = nullptr;
+  s->desc.streams = nullptr;
+  Bump b;
+  for (uint32_t i = 0; i < d->n_streams; i++) {
+    const orcgpu_stream& in = d->streams[i];
+    StagedStream st;
+    st.column_id = in.column_id;
+    st.kind = in.kind;
+    st.len = in.len;
+    st.off = b.take(in.len + ORC_PAD);
+    s->stream_bytes += in.len;
+    if (d->compression != ORCGPU_COMP_NONE) {
+      // chunk framing scan on the host while the bytes are at hand (compression.rs:113-123, :244-267)
+      uint64_t p = 0;
+      while (p < in.len) {
+        if (p + 3 > in.len) {
+          st.framing_error = true;
+          break;
+        }
+        uint32_t h = (uint32_t)in.ptr[p] | ((uint32_t)in.ptr[p + 1] << 8) | ((uint32_t)in.ptr[p + 2] << 16);
+        uint32_t len = h >> 1;
+        if (p + 3 + len > in.len) {
+          st.framing_error = true;
+          break;
+        }
+        st.chunks.push_back(ChunkInfo{p + 3, len, h & 1});
+        p += 3 + (uint64_t)len;
+      }
+      st.framed_len = p;
+    }
+    s->streams.push_back(std::move(st));
+  }
+  s->dev_bytes = align_up(b.off + ORC_PAD);
+  if (hipMalloc((void**)&s->dev, s->dev_bytes) != hipSuccess) {
+    set_err(ctx, "hipMalloc(%zu) for the staged stripe failed", s->dev_bytes);
+    delete s;
+    return ORCGPU_HIP_ERROR;
+  }
+  if (!ctx->ensure_pinned(s->dev_bytes)) {
+    set_err(ctx, "hipHostMalloc(%zu) failed", s->dev_bytes);
+    (void)hipFree(s->dev);
+    delete s;
+    return ORCGPU_HIP_ERROR;
+  }
+  // pinned bounce buffer -> one hipMemcpyAsync for the whole stripe
+  (void)hipStreamSynchronize(ctx->stream);  // the bounce buffer may still feed an earlier copy
+  for (uint32_t i = 0; i < d->n_streams; i++) {
+    if (d->streams[i].len) memcpy(ctx->pinned + s->streams[i].off, d->streams[i].ptr, d->streams[i].len);
+    memset(ctx->pinned + s->streams[i].off + d->streams[i].len, 0, ORC_PAD);
+  }
+  hipError_t e = b.off ? hipMemcpyAsync(s->dev, ctx->pinned, b.off, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    set_err(ctx, "staging copy failed: %s", hipGetErrorString(e));
+    (void)hipFree(s->dev);
+    delete s;
+    return ORCGPU_HIP_ERROR;
+  }
+  *out = s;
+  return ORCGPU_OK;
+}
+
+void orcgpu_staged_free(orcgpu_staged* s) {
+  if (!s) return;
+  if (s->dev) (void)hipFree(s->dev);
+  delete s;
+}
+uint64_t orcgpu_staged_bytes(const orcgpu_staged* s) { return s ? s->stream_bytes : 0; }
+
+}  // extern "C"
+
+// =================================================================================================
+namespace {
+
+// Resolve one stream of a column into a PlainStream (device pointer or scratch slot to decompress into)
+PlainStream plan_stream(Plan& P, orcgpu_staged* s, uint32_t col, int kind) {
+  PlainStream ps;
+  const StagedStream* st = s->find(col, kind);
+  if (!st) {
+    // StreamMap::get: a missing stream is an empty stream (stripe.rs:319-326)
+    ps.exists = false;
+    ps.dev = s->dev;  // any valid pointer; length 0
+    ps.len_upper = 0;
+    ps.len_idx = P.new_scalar(0);
+    return ps;
+  }
+  ps.exists = true;
+  if (s->desc.compression == ORCGPU_COMP_NONE) {
+    ps.dev = s->dev + st->off;
+    ps.len_upper = st->len;
+    ps.len_idx = P.new_scalar(st->len);
+  } else {
+    uint64_t upper = 0;
+    for (auto& c : st->chunks) upper += c.original ? c.len : s->desc.block_size;
+    ps.len_upper = upper;
+    ps.scratch_off = P.scratch.take(upper + ORC_PAD);
+    ps.len_idx = P.new_scalar(0);  // written by the decompress finalize kernel
+  }
+  return ps;
+}
+
+int add_job(Plan& P, int cls, uint8_t codec, bool is_signed, uint8_t nbits, uint8_t out_bytes, const PlainStream& ps, uint32_t needed_idx,
+            uint64_t expect_values, int stripe, int col, int role) {
+  JobPlan j{};
+  j.cls = cls;
+  j.codec = codec;
+  j.is_signed = is_signed;
+  j.nbits = nbits;
+  j.out_bytes = out_bytes;
+  j.data = ps.dev;
+  j.data_scratch_off = ps.scratch_off;
+  j.len_upper = ps.len_upper;
+  j.len_idx = ps.len_idx;
+  j.needed_idx = needed_idx;
+  j.total_idx = P.new_scalar(0);
+  j.expect_values = expect_values;
+  j.stripe = stripe;
+  j.col = col;
+  j.role = role;
+  P.jobs.push_back(j);
+  return (int)P.jobs.size() - 1;
+}
+
+template <typename... Args>
+hipError_t launch(void (*kernel)(Args...), uint64_t nthreads_or_blocks, bool is_blocks, uint32_t bs, hipStream_t st, Args... args) {
+  uint64_t grid = is_blocks ? nthreads_or_blocks : (nthreads_or_blocks + bs - 1) / bs;
+  if (grid == 0) return hipSuccess;
+  hipLaunchKernelGGL(kernel, dim3((uint32_t)grid), dim3(bs), 0, st, args...);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+#include "orcgpu_ext.inc"
+#include "orcgpu_decode.inc"
+#include "orcgpu_export.inc"

@@ -1,0 +1,122 @@
+"""Synthetic ORC stream generator (ctypes binding of gen/orcgen.c, built with gcc in-tree).
+
+Host-side test/benchmark tooling: produces encoded RLE v2 / v1 / byte-RLE / boolean / varint
+streams and ORC-framed Snappy / LZ4 chunks for the configs of BASELINE.md.  Not on the decode
+path."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "orcgen.c")
+SO = os.path.join(HERE, "liborcgen.so")
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(SO) or os.path.getmtime(SRC) > os.path.getmtime(SO):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-o", SO, SRC])
+    return SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        pp, ps = C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)
+        L.orcgen_rle2.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, pp, ps, C.c_void_p]
+        L.orcgen_rle1.argtypes = [C.c_void_p, C.c_size_t, C.c_int, pp, ps]
+        L.orcgen_byte_rle.argtypes = [C.c_void_p, C.c_size_t, pp, ps]
+        L.orcgen_bool.argtypes = [C.c_void_p, C.c_size_t, pp, ps]
+        L.orcgen_varint128.argtypes = [C.c_void_p, C.c_size_t, pp, ps]
+        L.orcgen_compress_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, pp, ps]
+        L.orcgen_free.argtypes = [C.c_void_p]
+        L.orcgen_splitmix64.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def _take(out, n):
+    buf = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1),))[:n.value].copy()
+    lib().orcgen_free(out)
+    return buf
+
+
+def rle2(values, signed=True, aligned=True, stats=False):
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    out, n = C.c_void_p(), C.c_size_t()
+    st = np.zeros(4, dtype=np.uint64)
+    lib().orcgen_rle2(v.ctypes.data, v.size, int(signed), int(aligned), C.byref(out), C.byref(n), st.ctypes.data)
+    buf = _take(out, n)
+    return (buf, dict(zip(("short_repeat", "direct", "patched_base", "delta"), st.tolist()))) if stats else buf
+
+
+def rle1(values, signed=True):
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    out, n = C.c_void_p(), C.c_size_t()
+    lib().orcgen_rle1(v.ctypes.data, v.size, int(signed), C.byref(out), C.byref(n))
+    return _take(out, n)
+
+
+def byte_rle(values):
+    v = np.ascontiguousarray(values).view(np.uint8)
+    out, n = C.c_void_p(), C.c_size_t()
+    lib().orcgen_byte_rle(v.ctypes.data, v.size, C.byref(out), C.byref(n))
+    return _take(out, n)
+
+
+def boolean(values):
+    v = np.ascontiguousarray(values, dtype=np.uint8)
+    out, n = C.c_void_p(), C.c_size_t()
+    lib().orcgen_bool(v.ctypes.data, v.size, C.byref(out), C.byref(n))
+    return _take(out, n)
+
+
+def varint128(values):
+    """values: iterable of Python ints (signed, |v| < 2**127)."""
+    arr = np.zeros(2 * len(values), dtype=np.uint64)
+    for i, x in enumerate(values):
+        u = x & ((1 << 128) - 1)
+        arr[2 * i] = u & ((1 << 64) - 1)
+        arr[2 * i + 1] = u >> 64
+    out, n = C.c_void_p(), C.c_size_t()
+    lib().orcgen_varint128(arr.ctypes.data, len(values), C.byref(out), C.byref(n))
+    return _take(out, n)
+
+
+def compress_stream(data, kind, block_size=262144):
+    """ORC chunk framing around greedy Snappy ('snappy') / LZ4 ('lz4') blocks, zlib raw deflate
+    ('zlib', Python's zlib) or Zstandard frames ('zstd', pyarrow.Codec when available)."""
+    d = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8))
+    if kind in ("snappy", "lz4"):
+        out, n = C.c_void_p(), C.c_size_t()
+        lib().orcgen_compress_stream(d.ctypes.data, d.size, 2 if kind == "snappy" else 4, block_size, C.byref(out), C.byref(n))
+        return _take(out, n)
+    raw = d.tobytes()
+    parts = []
+    for p in range(0, len(raw), block_size):
+        blk = raw[p:p + block_size]
+        if kind == "zlib":
+            import zlib
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            comp = c.compress(blk) + c.flush()
+        elif kind == "zstd":
+            import pyarrow as pa
+            comp = pa.Codec("zstd", compression_level=3).compress(blk, asbytes=True)
+        else:
+            raise ValueError(kind)
+        if len(comp) < len(blk):
+            h = len(comp) << 1
+            parts.append(bytes([h & 0xFF, (h >> 8) & 0xFF, (h >> 16) & 0xFF]) + comp)
+        else:
+            h = (len(blk) << 1) | 1
+            parts.append(bytes([h & 0xFF, (h >> 8) & 0xFF, (h >> 16) & 0xFF]) + blk)
+    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+
+
+def splitmix64(seed, n):
+    out = np.zeros(n, dtype=np.uint64)
+    lib().orcgen_splitmix64(seed, out.ctypes.data, n)
+    return out
