@@ -33,4 +33,5 @@ struct RleBlocks {
   uint32_t* nvals;      // values produced by runs that START in the block
   uint32_t* voff;       // exclusive prefix of nvals inside the block's scan tile
   uint32_t* tile_base;  // per tile: values before the tile (within the job)
+  uint8_t* flags;       // 1 = strong: entry verified by the candidate search (or filled by a strong owner)
 };

@@ -4,16 +4,24 @@
 // run after run from rle.rs:68-107; rle_v1.rs:143-159; byte.rs:228-247).  Run boundaries are
 // data dependent, so the stream is cut into RLE_BLK-byte blocks and one LANE walks one block:
 //
-//   round 0   every block guesses where its first header is (a multiple of the stream's first
-//             run size -- exact for the long regular runs ORC writers emit) and walks its runs;
-//   round r   block b takes exit[b-1] as its entry and re-walks only if that differs from the
-//             entry it used.  Short/irregular runs re-synchronise within a few hops, so the
-//             iteration converges in 2-4 rounds (chaotic relaxation: reading a neighbour's old
-//             or new exit are both fine, the fixed point is unique);
-//   verify    records the first inconsistent block per stream; rle_repair then fixes what is
-//             left with a serial walk (irregular long runs), so the result is always exact.
+//   guess     every block looks for a run header INSIDE ITS OWN BYTES without knowing the chain:
+//             a "full run" header (RLE v2: length field 512, not SHORT_REPEAT; byte RLE / RLE v1:
+//             a 128-literal group) that is followed by two (three) more headers of the same
+//             kind is accepted -- a random payload position passes with probability < 2^-30.
+//             Such a block is STRONG.  Blocks that find none fall back to offset 0 (WEAK): in
+//             short-run regions a wrong entry re-synchronises with the true chain within a few
+//             hops, so the guess is usually harmless there;
+//   fill      a strong block whose last run covers whole following blocks marks them as
+//             pass-through (their entry = distance to the next header);
+//   relax     a weak block takes exit[b-1] as its entry and re-walks if that differs from what it
+//             used (chaotic relaxation; the fixed point is unique).  Strong blocks keep their
+//             entry, so garbage from a weak neighbour cannot destroy them;
+//   verify    every block compares its entry with exit[b-1]; the first mismatch per stream is
+//             recorded and rle_repair walks the true chain from there.  The result is exact
+//             whatever the heuristics did.
 //
-// Traffic: only header bytes are read (payload is skipped); per block 16 B of state.
+// Traffic: header bytes of every run, plus one pass over the stream by the candidate search
+// (skipped when the stride guess from the stream's first run is already verified).
 #include "rle_kernels.h"
 #include "rle_parse.h"
 
@@ -51,7 +59,63 @@ __device__ __forceinline__ void walk_dispatch(const RleJob* j, const uint8_t* da
   else walk_block<CODEC_BYTE>(data, len, lb, entry, false, 8, ex, nv);
 }
 
-// mode 0: first round (stride guess); 1: relaxation round; 2: verify only
+// A "full run" header at p that is followed by `hops` more headers of the same kind.
+template <int CODEC>
+__device__ __forceinline__ bool plausible_header(const uint8_t* data, uint64_t len, uint64_t p, bool is_signed, int nbits) {
+  RunHdr h;
+  run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, h);
+  if (h.err) return false;
+  if (CODEC == CODEC_RLE2) {
+    if (h.n != 512 || h.type == RT_SR) return false;
+  } else {
+    if (h.n != 128 || (h.type != RT_B_LIT && h.type != RT_V1_LIT)) return false;
+  }
+  uint64_t q = p + h.size;
+  const int hops = CODEC == CODEC_RLE2 ? 2 : 3;
+  for (int i = 0; i < hops; i++) {
+    if (q == len) return true;
+    RunHdr g;
+    run_parse<CODEC, false>(data + q, len - q, is_signed, nbits, g);
+    if (g.err || g.n != h.n || g.type != h.type) return false;
+    q += g.size;
+  }
+  return true;
+}
+
+// First verified full-run header inside block lb, or RLE_BLK when none is found.
+template <int CODEC>
+__device__ __forceinline__ uint32_t find_candidate(const uint8_t* data, uint64_t len, uint32_t lb, uint32_t stride_guess, bool is_signed,
+                                                   int nbits) {
+  const uint64_t b0 = (uint64_t)lb * RLE_BLK;
+  const uint64_t bend = b0 + RLE_BLK < len ? b0 + RLE_BLK : len;
+  if (stride_guess < RLE_BLK && b0 + stride_guess < bend && plausible_header<CODEC>(data, len, b0 + stride_guess, is_signed, nbits))
+    return stride_guess;
+  int tries = 0;
+  for (uint64_t p = b0; p < bend; p += 8) {
+    uint64_t w = ld_u64(data + p);
+    uint64_t m;
+    if (CODEC == CODEC_RLE2) {
+      // byte i: low bit set (length bit 8), type != SHORT_REPEAT, and byte i+1 == 0xFF (length low byte)
+      uint64_t nx = ~ld_u64(data + p + 1);
+      uint64_t ff = (nx - 0x0101010101010101ull) & ~nx & 0x8080808080808080ull;  // bytes of the next word equal to 0xFF
+      m = ff & ((w & 0x0101010101010101ull) << 7) & ((w | (w << 1)) & 0x8080808080808080ull);
+    } else {
+      uint64_t x = w ^ 0x8080808080808080ull;  // header byte 0x80 = 128 literals
+      m = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+    }
+    while (m) {
+      uint32_t i = (uint32_t)__builtin_ctzll(m) >> 3;
+      m &= m - 1;
+      uint64_t c = p + i;
+      if (c >= bend) break;
+      if (plausible_header<CODEC>(data, len, c, is_signed, nbits)) return (uint32_t)(c - b0);
+      if (++tries >= 6) return RLE_BLK;
+    }
+  }
+  return RLE_BLK;
+}
+
+// mode 0: guess; 1: relaxation round; 2: verify only; 3: strong blocks fill their pass-through blocks
 extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
                                                                    uint32_t total_blocks, int mode) {
   uint32_t b = blockIdx.x * 256u + threadIdx.x;
@@ -65,23 +129,51 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
       blk.entry[b] = RLE_BLK;
       blk.exit_[b] = 0;
       blk.nvals[b] = 0;
+      blk.flags[b] = 0;
     }
     return;
   }
   const uint8_t* data = j->data;
+  if (mode == 3) {
+    // a strong block whose last run extends over whole following blocks owns them
+    if (!blk.flags[b]) return;
+    uint32_t ex = blk.exit_[b];
+    uint32_t nbk = j->nblocks;
+    for (uint32_t pb = lb + 1; ex >= RLE_BLK && pb < nbk; pb++, ex -= RLE_BLK) {
+      if ((uint64_t)pb * RLE_BLK >= len) break;
+      blk.entry[b - lb + pb] = ex;
+      blk.exit_[b - lb + pb] = ex - RLE_BLK;
+      blk.nvals[b - lb + pb] = 0;
+      blk.flags[b - lb + pb] = 1;
+    }
+    return;
+  }
   uint32_t want;
+  uint32_t strong = 0;
   if (lb == 0) {
     want = 0;
+    strong = 1;
   } else if (mode == 0) {
-    // stride guess from the stream's first run
+    // stride guess from the stream's first run, then the candidate search
     RunHdr h;
     if (j->codec == CODEC_RLE2) run_parse<CODEC_RLE2, false>(data, len, j->is_signed, j->nbits, h);
     else if (j->codec == CODEC_RLE1) run_parse<CODEC_RLE1, false>(data, len, j->is_signed, j->nbits, h);
     else run_parse<CODEC_BYTE, false>(data, len, false, 8, h);
     uint32_t s0 = h.size ? h.size : 1;
     uint32_t r = (uint32_t)(((uint64_t)lb * RLE_BLK) % s0);
-    want = r ? s0 - r : 0;
+    uint32_t sg = r ? s0 - r : 0;
+    uint32_t cand;
+    if (j->codec == CODEC_RLE2) cand = find_candidate<CODEC_RLE2>(data, len, lb, sg, j->is_signed, j->nbits);
+    else if (j->codec == CODEC_RLE1) cand = find_candidate<CODEC_RLE1>(data, len, lb, sg, j->is_signed, j->nbits);
+    else cand = find_candidate<CODEC_BYTE>(data, len, lb, sg, false, 8);
+    if (cand < RLE_BLK) {
+      want = cand;
+      strong = 1;
+    } else {
+      want = 0;
+    }
   } else {
+    if (mode == 1 && blk.flags[b]) return;  // strong blocks hold their entry
     want = blk.exit_[b - 1];
   }
   if (mode != 0 && want == blk.entry[b]) return;
@@ -99,59 +191,130 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
   blk.entry[b] = want;
   blk.exit_[b] = ex;
   blk.nvals[b] = nv;
+  if (mode == 0) blk.flags[b] = (uint8_t)strong;
 }
 
-// Serial repair of whatever the relaxation rounds left inconsistent: one wavefront per job,
-// lane 0 walks, all lanes help re-verifying 64 blocks at a time after a re-synchronisation.
+// Repair of whatever the relaxation rounds left inconsistent (long runs of irregular size never
+// re-synchronise from a wrong guess).  One wavefront per stream walks the true chain from the
+// first inconsistent block:
+//   * runs of at least RLE_BLK bytes: STRIDE SPECULATION -- lane i of 4 x 64 candidates parses a
+//     header at pos + i*s (s = size of the run at pos); a ballot finds the first candidate whose
+//     size differs, every candidate before it is a proven header, so up to 256 runs are resolved
+//     per memory round trip.  Each proven header owns its block (one header per block because
+//     s >= RLE_BLK) and the pass-through blocks up to the next header;
+//   * shorter runs: lane 0 walks the block serially (the relaxation rounds normally handle these).
+// The walk stops early when it lands on a block whose stored entry is already right and no later
+// block is inconsistent.
+template <int CODEC>
+__device__ __forceinline__ void repair_chain(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t nb, uint32_t lane) {
+  const uint8_t* data = j->data;
+  const bool is_signed = j->is_signed;
+  const int nbits = j->nbits;
+  const uint32_t b0 = j->block0;
+  uint32_t fill_from = j->first_bad;  // blocks below are final; [fill_from, block(pos)) are pass-through
+  uint64_t pos = (uint64_t)fill_from * RLE_BLK + (fill_from == 0 ? 0u : blk.exit_[b0 + fill_from - 1]);
+  for (;;) {
+    uint32_t lb = pos < len ? (uint32_t)(pos / RLE_BLK) : nb;
+    if (lb > nb) lb = nb;
+    // pass-through blocks between the last finished block and the block of the next header
+    for (uint32_t pb = fill_from + lane; pb < lb; pb += 64) {
+      uint64_t e = pos - (uint64_t)pb * RLE_BLK;  // >= RLE_BLK except in the stream's last block
+      blk.entry[b0 + pb] = (uint32_t)e;
+      blk.exit_[b0 + pb] = e >= RLE_BLK ? (uint32_t)(e - RLE_BLK) : 0u;
+      blk.nvals[b0 + pb] = 0;
+    }
+    if (lb >= nb) return;
+    fill_from = lb;
+    uint32_t want = (uint32_t)(pos - (uint64_t)lb * RLE_BLK);
+    if (blk.entry[b0 + lb] == want) {
+      // consistent here: find the next inconsistent block, 64 at a time.  Everything read below
+      // was written by earlier launches (this kernel only ever writes blocks below `lb`).
+      uint32_t next = nb;
+      for (uint32_t s = lb + 1; s < nb; s += 64) {
+        uint32_t c = s + lane;
+        bool mism = false;
+        if (c < nb) mism = blk.exit_[b0 + c - 1] != blk.entry[b0 + c];
+        unsigned long long m = __ballot(mism);
+        if (m) {
+          next = s + (uint32_t)__builtin_ctzll(m);
+          break;
+        }
+      }
+      if (next >= nb) return;
+      fill_from = next;
+      pos = (uint64_t)next * RLE_BLK + blk.exit_[b0 + next - 1];
+      continue;
+    }
+    RunHdr h0;
+    run_parse<CODEC, false>(data + pos, len - pos, is_signed, nbits, h0);
+    const uint32_t s = h0.size;
+    if (s >= RLE_BLK && !h0.err) {
+      // ---- stride speculation over 256 candidates ----
+      uint32_t first_fail = 256;
+      uint32_t nv[4];
+      for (int k = 0; k < 4; k++) {
+        uint64_t c = pos + (uint64_t)(k * 64 + lane) * s;
+        bool ok = false;
+        nv[k] = 0;
+        if (c < len) {
+          RunHdr h;
+          run_parse<CODEC, false>(data + c, len - c, is_signed, nbits, h);
+          ok = !h.err && h.size == s;
+          nv[k] = h.n;
+        }
+        unsigned long long bad = __ballot(!ok);
+        if (bad && first_fail == 256) first_fail = k * 64 + (uint32_t)__builtin_ctzll(bad);
+      }
+      // candidates [0, first_fail) are proven headers of size s >= RLE_BLK: one header per block
+      for (int k = 0; k < 4; k++) {
+        uint32_t i = k * 64 + lane;
+        if (i < first_fail) {
+          uint64_t c = pos + (uint64_t)i * s;
+          uint32_t hb = (uint32_t)(c / RLE_BLK);
+          uint64_t nextpos = c + s;
+          if (hb < nb) {
+            uint64_t bend = (uint64_t)(hb + 1) * RLE_BLK;
+            blk.entry[b0 + hb] = (uint32_t)(c - (uint64_t)hb * RLE_BLK);
+            blk.nvals[b0 + hb] = nv[k];
+            blk.exit_[b0 + hb] = nextpos > bend ? (uint32_t)(nextpos - bend) : 0u;
+          }
+          for (uint32_t pb = hb + 1; (uint64_t)(pb + 1) * RLE_BLK <= nextpos && pb < nb; pb++) {
+            uint32_t e = (uint32_t)(nextpos - (uint64_t)pb * RLE_BLK);
+            blk.entry[b0 + pb] = e;
+            blk.exit_[b0 + pb] = e - RLE_BLK;
+            blk.nvals[b0 + pb] = 0;
+          }
+        }
+      }
+      pos += (uint64_t)first_fail * s;
+      uint64_t fb = pos / RLE_BLK;
+      fill_from = fb < nb ? (uint32_t)fb : nb;
+    } else {
+      // ---- short (or failing) run: lane 0 walks the whole block ----
+      uint32_t ex = 0, nvv = 0;
+      if (lane == 0) {
+        walk_block<CODEC>(data, len, lb, want, is_signed, nbits, &ex, &nvv);
+        blk.entry[b0 + lb] = want;
+        blk.exit_[b0 + lb] = ex;
+        blk.nvals[b0 + lb] = nvv;
+      }
+      ex = __shfl(ex, 0);
+      pos = (uint64_t)(lb + 1) * RLE_BLK + ex;
+      fill_from = lb + 1;
+    }
+  }
+}
+
 extern "C" __global__ void __launch_bounds__(64) rle_repair_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars) {
   RleJob* j = &jobs[blockIdx.x];
   uint32_t lane = threadIdx.x;
-  uint32_t bad = j->first_bad;
-  if (bad == 0xffffffffu) return;
+  if (j->first_bad == 0xffffffffu) return;
   uint64_t len = scalars[j->len_idx];
   uint32_t nb = (uint32_t)((len + RLE_BLK - 1) / RLE_BLK);
   if (nb > j->nblocks) nb = j->nblocks;
-  const uint8_t* data = j->data;
-  // Everything this kernel READS from the block arrays was written by earlier launches: the
-  // exit of a block repaired here is carried in a register, never re-read.
-  uint32_t lb = bad;
-  uint32_t b0 = j->block0;
-  uint32_t prev_exit = lb == 0 ? 0u : blk.exit_[b0 + lb - 1];
-  while (lb < nb) {
-    uint32_t b = b0 + lb;
-    uint32_t want = lb == 0 ? 0u : prev_exit;
-    if (want != blk.entry[b]) {
-      uint32_t ex = 0, nv = 0;
-      if (lane == 0) {
-        if (want >= RLE_BLK) {
-          ex = want - RLE_BLK;
-        } else {
-          walk_dispatch(j, data, len, lb, want, &ex, &nv);
-        }
-        blk.entry[b] = want;
-        blk.exit_[b] = ex;
-        blk.nvals[b] = nv;
-      }
-      prev_exit = __shfl(ex, 0);
-      lb++;
-      continue;
-    }
-    // consistent here: look for the next inconsistent block, 64 at a time
-    uint32_t next = nb;
-    for (uint32_t s = lb + 1; s < nb; s += 64) {
-      uint32_t c = s + lane;
-      bool mism = false;
-      if (c < nb) mism = blk.exit_[b0 + c - 1] != blk.entry[b0 + c];
-      unsigned long long m = __ballot(mism);
-      if (m) {
-        next = s + (uint32_t)__builtin_ctzll(m);
-        break;
-      }
-    }
-    lb = next;
-    if (lb < nb) prev_exit = blk.exit_[b0 + lb - 1];
-  }
-  if (lane == 0) j->first_bad = 0xffffffffu;
+  if (j->codec == CODEC_RLE2) repair_chain<CODEC_RLE2>(j, blk, len, nb, lane);
+  else if (j->codec == CODEC_RLE1) repair_chain<CODEC_RLE1>(j, blk, len, nb, lane);
+  else repair_chain<CODEC_BYTE>(j, blk, len, nb, lane);
 }
 
 // Exclusive scan of nvals inside each RLE_TILE-block tile (one workgroup per tile).
