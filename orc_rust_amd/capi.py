@@ -235,9 +235,8 @@ class Result:
     def export_batch(self, batch):
         """Arrow C Data Interface export -> pyarrow.RecordBatch (zero-copy import of host buffers)."""
         import pyarrow as pa
-        from pyarrow.cffi import ffi
-        a = ffi.new("struct ArrowArray*")
-        s = ffi.new("struct ArrowSchema*")
-        pa_ptr, ps_ptr = int(ffi.cast("uintptr_t", a)), int(ffi.cast("uintptr_t", s))
+        a = (C.c_uint8 * 80)()   # struct ArrowArray  (10 x 8 bytes)
+        s = (C.c_uint8 * 72)()   # struct ArrowSchema (9 x 8 bytes)
+        pa_ptr, ps_ptr = C.addressof(a), C.addressof(s)
         self.ctx._check(self.ctx.L.orcgpu_result_export_batch(self.ctx.h, self.h, batch, pa_ptr, ps_ptr))
         return pa.RecordBatch._import_from_c(pa_ptr, ps_ptr)

@@ -1,0 +1,265 @@
+// inflate_device.h -- raw DEFLATE (RFC 1951) for one wavefront.  Replaces flate2's DeflateDecoder
+// at compression.rs:142-149.  The Huffman token stream is decoded wave-uniformly through a
+// 10-bit fast table in LDS (longer codes fall back to canonical bit-by-bit decoding); literal
+// bytes are stored by lane 0, matches are copied by all lanes.
+#pragma once
+
+struct HuffTab {
+  uint16_t fast[1024];  // (len << 12) | symbol for codes of <= 10 bits, 0 = long code
+  uint16_t count[16];
+  uint16_t symbol[320];
+};
+
+struct FseEnt {
+  uint8_t sym, nb;
+  uint16_t base;
+};
+
+struct DecompLds {
+  union {
+    struct {
+      HuffTab lit, dist;
+      uint8_t lens[320];
+    } inf;
+    struct {
+      FseEnt ll[512], ml[512], of[256], wt[64];
+      uint16_t huf[2048];      // sym | nb << 8
+      uint8_t weights[256];
+      int16_t norm[256];
+      uint16_t next[256];
+    } z;
+  };
+};
+
+struct BitRd {
+  const uint8_t* src;
+  uint32_t n, pos;
+  uint64_t bb;
+  uint32_t bc;
+};
+__device__ __forceinline__ void br_refill(BitRd& b) {
+  // bytes past the end are garbage; overrun is detected at block boundaries via br_overrun()
+  b.bb |= ld_u64(b.src + b.pos) << b.bc;
+  uint32_t adv = (63 - b.bc) >> 3;
+  b.pos += adv;
+  b.bc += adv * 8;
+}
+__device__ __forceinline__ uint32_t br_get(BitRd& b, uint32_t k) {
+  if (b.bc < k) br_refill(b);
+  uint32_t v = (uint32_t)(b.bb & ((1ull << k) - 1));
+  b.bb >>= k;
+  b.bc -= k;
+  return v;
+}
+__device__ __forceinline__ bool br_overrun(const BitRd& b) { return (uint64_t)b.pos * 8 - b.bc > (uint64_t)b.n * 8; }
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t len) { return __builtin_bitreverse32(v) >> (32 - len); }
+
+// canonical Huffman from code lengths; returns <0 over-subscribed, 0 complete, >0 incomplete
+__device__ __forceinline__ int huff_build_dev(HuffTab& h, const uint8_t* lens, int n, uint32_t lane) {
+  for (uint32_t i = lane; i < 1024; i += 64) h.fast[i] = 0;
+  if (lane < 16) h.count[lane] = 0;
+  wave_sync();
+  int left = 0;
+  if (lane == 0) {
+    for (int i = 0; i < n; i++) h.count[lens[i]]++;
+    uint16_t offs[16];
+    left = 1;
+    int bad = 0;
+    if (h.count[0] == n) {
+      left = 0;
+    } else {
+      for (int len = 1; len < 16; len++) {
+        left <<= 1;
+        left -= h.count[len];
+        if (left < 0) {
+          bad = 1;
+          break;
+        }
+      }
+      if (!bad) {
+        offs[1] = 0;
+        for (int len = 1; len < 15; len++) offs[len + 1] = offs[len] + h.count[len];
+        for (int i = 0; i < n; i++)
+          if (lens[i]) h.symbol[offs[lens[i]]++] = (uint16_t)i;
+        // fast table
+        uint32_t code = 0, idx = 0;
+        for (uint32_t len = 1; len <= 10; len++) {
+          for (uint32_t k = 0; k < h.count[len]; k++, idx++, code++) {
+            uint32_t sym = h.symbol[idx];
+            uint32_t r = bitrev(code, len);
+            for (uint32_t j = r; j < 1024; j += 1u << len) h.fast[j] = (uint16_t)((len << 12) | sym);
+          }
+          code <<= 1;
+        }
+      }
+    }
+    if (bad) left = -1;
+  }
+  left = __shfl(left, 0);
+  wave_sync();
+  return left;
+}
+
+__device__ __forceinline__ int huff_decode_dev(BitRd& b, const HuffTab& h) {
+  if (b.bc < 15) br_refill(b);
+  uint32_t e = h.fast[b.bb & 1023];
+  if (e) {
+    uint32_t l = e >> 12;
+    b.bb >>= l;
+    b.bc -= l;
+    return (int)(e & 0xfff);
+  }
+  // long code: canonical decoding one bit at a time
+  int code = 0, first = 0, index = 0;
+  uint64_t bits = b.bb;
+  for (int len = 1; len < 16; len++) {
+    code |= (int)(bits & 1);
+    bits >>= 1;
+    int count = h.count[len];
+    if (code - count < first) {
+      b.bb >>= len;
+      b.bc -= len;
+      return h.symbol[index + (code - first)];
+    }
+    index += count;
+    first += count;
+    first <<= 1;
+    code <<= 1;
+  }
+  return -1;
+}
+
+__device__ const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__device__ const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ const uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ int inflate_codes_dev(BitRd& b, uint8_t* dst, uint32_t cap, uint64_t& out, const HuffTab& lc, const HuffTab& dc,
+                                                  uint32_t lane) {
+  for (;;) {
+    int sym = huff_decode_dev(b, lc);
+    if (sym < 0) return 1;
+    if (sym < 256) {
+      if (out >= cap) return 1;
+      if (lane == 0) dst[out] = (uint8_t)sym;
+      out++;
+    } else if (sym == 256) {
+      return br_overrun(b) ? 1 : 0;
+    } else {
+      sym -= 257;
+      if (sym >= 29) return 1;
+      uint32_t len = LBASE[sym] + br_get(b, LEXT[sym]);
+      int ds = huff_decode_dev(b, dc);
+      if (ds < 0 || ds >= 30) return 1;
+      uint32_t dist = DBASE[ds] + br_get(b, DEXT[ds]);
+      if (dist > out || out + len > cap) return 1;
+      wave_fence();
+      wave_match(dst, out, dist, len, lane);
+      out += len;
+    }
+    if (br_overrun(b)) return 1;
+  }
+}
+
+__device__ __forceinline__ int inflate_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t lane, uint32_t* out_len,
+                                             DecompLds& L) {
+  BitRd b{src, n, 0, 0, 0};
+  uint64_t out = 0;
+  uint32_t last;
+  do {
+    last = br_get(b, 1);
+    uint32_t type = br_get(b, 2);
+    if (br_overrun(b)) return 1;
+    if (type == 0) {
+      // stored: skip to the byte boundary; bits still buffered belong to the bytes before pos
+      uint32_t drop = b.bc & 7;
+      b.bb >>= drop;
+      b.bc -= drop;
+      uint32_t bytepos = b.pos - (b.bc >> 3);
+      if (bytepos + 4 > n) return 1;
+      uint32_t len = src[bytepos] | (src[bytepos + 1] << 8);
+      uint32_t nlen = src[bytepos + 2] | (src[bytepos + 3] << 8);
+      bytepos += 4;
+      if ((len ^ 0xffffu) != nlen) return 1;
+      if (bytepos + len > n || out + len > cap) return 1;
+      wave_copy(dst + out, src + bytepos, len, lane);
+      out += len;
+      b.pos = bytepos + len;
+      b.bb = 0;
+      b.bc = 0;
+    } else if (type == 1) {
+      for (uint32_t i = lane; i < 288; i += 64) L.inf.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+      wave_sync();
+      huff_build_dev(L.inf.lit, L.inf.lens, 288, lane);
+      for (uint32_t i = lane; i < 30; i += 64) L.inf.lens[i] = 5;
+      wave_sync();
+      huff_build_dev(L.inf.dist, L.inf.lens, 30, lane);
+      if (inflate_codes_dev(b, dst, cap, out, L.inf.lit, L.inf.dist, lane)) return 1;
+    } else if (type == 2) {
+      uint32_t nlen = br_get(b, 5) + 257, ndist = br_get(b, 5) + 1, ncode = br_get(b, 4) + 4;
+      if (br_overrun(b) || nlen > 286 || ndist > 30) return 1;
+      // code-length code lengths: read uniformly, lane 0 stores
+      for (uint32_t i = lane; i < 19; i += 64) L.inf.lens[i] = 0;
+      wave_sync();
+      for (uint32_t i = 0; i < ncode; i++) {
+        uint32_t v = br_get(b, 3);
+        if (lane == 0) L.inf.lens[CLORDER[i]] = (uint8_t)v;
+      }
+      wave_sync();
+      if (huff_build_dev(L.inf.lit, L.inf.lens, 19, lane) != 0) return 1;
+      // literal/length + distance code lengths (decoded uniformly into registers-by-LDS)
+      uint32_t i = 0;
+      uint32_t prev = 0;
+      int fail = 0;
+      // lens[] is being rewritten while lit (the code-length code) is in use: lit only reads its own tables
+      while (i < nlen + ndist) {
+        int sym = huff_decode_dev(b, L.inf.lit);
+        if (sym < 0) {
+          fail = 1;
+          break;
+        }
+        if (sym < 16) {
+          if (lane == 0) L.inf.lens[i] = (uint8_t)sym;
+          prev = (uint32_t)sym;
+          i++;
+        } else {
+          uint32_t len = 0, rep;
+          if (sym == 16) {
+            if (i == 0) {
+              fail = 1;
+              break;
+            }
+            len = prev;
+            rep = 3 + br_get(b, 2);
+          } else if (sym == 17) {
+            rep = 3 + br_get(b, 3);
+          } else {
+            rep = 11 + br_get(b, 7);
+          }
+          if (i + rep > nlen + ndist) {
+            fail = 1;
+            break;
+          }
+          for (uint32_t k = lane; k < rep; k += 64) L.inf.lens[i + k] = (uint8_t)len;
+          prev = len;
+          i += rep;
+        }
+      }
+      if (fail || br_overrun(b)) return 1;
+      wave_sync();
+      if (L.inf.lens[256] == 0) return 1;
+      // the distance lengths follow the literal/length lengths: build dist first from lens + nlen, then lit
+      int r = huff_build_dev(L.inf.dist, L.inf.lens + nlen, (int)ndist, lane);
+      if (r < 0 || (r > 0 && (int)ndist - (int)L.inf.dist.count[0] != 1)) return 1;
+      r = huff_build_dev(L.inf.lit, L.inf.lens, (int)nlen, lane);
+      if (r < 0 || (r > 0 && (int)nlen - (int)L.inf.lit.count[0] != 1)) return 1;
+      if (inflate_codes_dev(b, dst, cap, out, L.inf.lit, L.inf.dist, lane)) return 1;
+    } else {
+      return 1;
+    }
+  } while (!last);
+  *out_len = (uint32_t)out;
+  return 0;
+}

@@ -1,2 +1,351 @@
-// string_kernels.hip -- String/Binary/Decimal finishers (filled in below the integer path).
+// string_kernels.hip -- String / Binary / Decimal finishers.
+//
+//   GenericByteArrayDecoder::next_byte_batch      array_decoder/string.rs:111-153
+//     lengths (unsigned RLE, spaced, 0 at nulls) -> per-batch int32 offsets restarting at 0,
+//     sum > i32::MAX -> OffsetOverflow, values = the next `sum` bytes of DATA, Utf8 validated
+//   DictionaryStringArrayDecoder::next_batch      array_decoder/string.rs:204-224
+//     keys (unsigned RLE, spaced) bounds-checked (DictionaryArray::try_new), cast to Utf8 =
+//     per-row gather of the dictionary entry, null rows get an empty string
+//   UnboundedVarintStreamDecoder + fix_i128_scale encoding/decimal.rs:28-52, array_decoder/decimal.rs:138-166
 #include "rle_parse.h"
+
+__device__ __forceinline__ void report_err64(unsigned long long* err, uint64_t idx, uint32_t code) {
+  atomicMin(err, ((unsigned long long)idx << 8) | code);
+}
+
+// ---- lengths / keys -> per-row int32 lengths ------------------------------------------------------
+// dense: int64 lengths (direct) or keys (dictionary) of the non-null rows.
+// dict_off == nullptr: direct strings.  rows with a negative length / key out of range raise Arrow.
+extern "C" __global__ void __launch_bounds__(256) string_lens_kernel(const int64_t* dense, const unsigned long long* vbits, const uint32_t* rank,
+                                                                      const int32_t* dict_off, const uint64_t* scalars, uint32_t dict_n_idx,
+                                                                      int32_t* lens, int32_t* keys, uint64_t n_rows, unsigned long long* err) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  uint64_t d = i;
+  bool valid = true;
+  if (vbits) {
+    unsigned long long word = vbits[i >> 6];
+    uint32_t bit = i & 63;
+    valid = (word >> bit) & 1;
+    d = (uint64_t)rank[i >> 6] + __builtin_popcountll(word & ((1ull << bit) - 1));
+  }
+  int32_t len = 0, key = 0;
+  if (valid) {
+    int64_t v = dense[d];
+    if (dict_off) {
+      uint64_t dict_n = scalars[dict_n_idx];
+      if (v < 0 || (uint64_t)v >= dict_n) {
+        report_err64(err, i, ORC_E_ARROW);
+      } else {
+        key = (int32_t)v;
+        len = dict_off[v + 1] - dict_off[v];
+      }
+    } else {
+      if (v < 0) report_err64(err, i, ORC_E_ARROW);
+      else if (v > 0x7fffffffll) {
+        report_err64(err, i, ORC_E_OFFSET_OVERFLOW);
+      } else {
+        len = (int32_t)v;
+      }
+    }
+  }
+  lens[i] = len;
+  if (keys) keys[i] = key;
+}
+
+// ---- per-batch exclusive scan of the lengths -> offsets (restart at 0 per batch) -------------------
+// One workgroup per batch.  offsets layout: batch b at b * (batch + 1).
+extern "C" __global__ void __launch_bounds__(256) batch_offsets_kernel(const int32_t* lens, uint64_t n_rows, uint32_t batch, int32_t* offsets,
+                                                                        unsigned long long* chartot, unsigned long long* err, uint32_t ovf_code) {
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t carry_s;
+  uint64_t b = blockIdx.x;
+  uint64_t row0 = b * batch;
+  uint64_t rows = n_rows - row0 < batch ? n_rows - row0 : batch;
+  int32_t* out = offsets + b * ((uint64_t)batch + 1);
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint64_t s = 0; s < rows; s += 256) {
+    uint64_t i = s + threadIdx.x;
+    uint64_t v = i < rows ? (uint64_t)(uint32_t)lens[row0 + i] : 0;
+    uint64_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint64_t t = __shfl_up(incl, o);
+      if ((int)(threadIdx.x & 63) >= o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t wbase = carry_s;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += wsum[w];
+    if (i < rows) out[i] = (int32_t)(wbase + incl - v);
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = wbase + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[rows] = (int32_t)carry_s;
+    chartot[b] = carry_s;
+    if (carry_s > 0x7fffffffull) report_err64(err, row0, ovf_code);
+  }
+}
+
+// exclusive scan of the per-batch totals (single workgroup) -> charbase[b]; grand total -> *total
+extern "C" __global__ void __launch_bounds__(256) batch_base_kernel(const unsigned long long* chartot, unsigned long long* charbase, uint32_t n_batches,
+                                                                     uint64_t* total) {
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t s = 0; s < n_batches; s += 256) {
+    uint32_t i = s + threadIdx.x;
+    uint64_t v = i < n_batches ? chartot[i] : 0;
+    uint64_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint64_t t = __shfl_up(incl, o);
+      if ((int)(threadIdx.x & 63) >= o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t wbase = carry_s;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += wsum[w];
+    if (i < n_batches) charbase[i] = wbase + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = wbase + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry_s;
+}
+
+// ---- dictionary -> Utf8 materialisation: one lane per row, bytes of the entry copied to the row's slot
+extern "C" __global__ void __launch_bounds__(256) dict_gather_kernel(const int32_t* keys, const int32_t* lens, const int32_t* offsets,
+                                                                      const unsigned long long* charbase, const int32_t* dict_off,
+                                                                      const uint8_t* dict_bytes, uint8_t* out, uint64_t n_rows, uint32_t batch) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  int32_t len = lens[i];
+  if (!len) return;
+  uint64_t b = i / batch;
+  uint64_t dst = charbase[b] + (uint64_t)(uint32_t)offsets[b * ((uint64_t)batch + 1) + (i - b * batch)];
+  const uint8_t* src = dict_bytes + dict_off[keys[i]];
+  uint8_t* d = out + dst;
+  int32_t k = 0;
+  for (; k + 8 <= len; k += 8) {
+    uint64_t v = ld_u64(src + k);
+    __builtin_memcpy(d + k, &v, 8);
+  }
+  for (; k < len; k++) d[k] = src[k];
+}
+
+// ---- dictionary lengths -> dictionary offsets (single workgroup; the dictionary is loaded once per stripe)
+extern "C" __global__ void __launch_bounds__(256) dict_offsets_kernel(const int64_t* dlens, const uint64_t* scalars, uint32_t dict_n_idx,
+                                                                       uint32_t data_len_idx, int32_t* dict_off, uint64_t* dict_bytes_out,
+                                                                       unsigned long long* err) {
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t carry_s;
+  __shared__ int bad_s;
+  uint64_t n = scalars[dict_n_idx];
+  if (threadIdx.x == 0) {
+    carry_s = 0;
+    bad_s = 0;
+  }
+  __syncthreads();
+  for (uint64_t s = 0; s < n; s += 256) {
+    uint64_t i = s + threadIdx.x;
+    int64_t l = i < n ? dlens[i] : 0;
+    if (l < 0) {
+      atomicOr(&bad_s, 1);
+      l = 0;
+    }
+    uint64_t v = (uint64_t)l;
+    uint64_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint64_t t = __shfl_up(incl, o);
+      if ((int)(threadIdx.x & 63) >= o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t wbase = carry_s;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += wsum[w];
+    uint64_t e = wbase + incl - v;
+    if (i < n) dict_off[i] = (int32_t)(e > 0x7fffffffull ? 0x7fffffff : e);
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = wbase + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    uint64_t total = carry_s;
+    dict_off[n] = (int32_t)(total > 0x7fffffffull ? 0x7fffffff : total);
+    *dict_bytes_out = total;
+    // construction errors fail the whole stripe decoder (new_string_decoder `?`, string.rs:70-72): index 0
+    if (total > 0x7fffffffull) report_err64(err, 0, ORC_E_OFFSET_OVERFLOW);
+    else if (bad_s) report_err64(err, 0, ORC_E_ARROW);
+    else if (total > scalars[data_len_idx]) report_err64(err, 0, ORC_E_ARROW);  // offsets past the values buffer (try_new)
+  }
+}
+
+// ---- UTF-8 validation (StringArray::try_new): every byte checks its own role ----------------------
+// err receives min(byte position << 8 | ORC_E_ARROW).  `n_idx` = scalar with the number of bytes to check.
+__device__ __forceinline__ int utf8_lead_len(uint8_t c) {
+  if (c < 0x80) return 1;
+  if (c >= 0xc2 && c <= 0xdf) return 2;
+  if (c >= 0xe0 && c <= 0xef) return 3;
+  if (c >= 0xf0 && c <= 0xf4) return 4;
+  return 0;  // continuation (0x80..0xbf) or invalid (0xc0, 0xc1, 0xf5..0xff)
+}
+extern "C" __global__ void __launch_bounds__(256) utf8_validate_kernel(const uint8_t* s, const uint64_t* scalars, uint32_t n_idx, uint64_t n_upper,
+                                                                        unsigned long long* err) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t n = scalars[n_idx];
+  if (n > n_upper) n = n_upper;
+  if (i >= n) return;
+  uint8_t c = s[i];
+  if (c < 0x80) return;
+  bool bad = false;
+  if ((c & 0xc0) == 0x80) {
+    // continuation byte: some lead within the previous 3 bytes must cover it
+    bool covered = false;
+    for (int k = 1; k <= 3 && (uint64_t)k <= i; k++) {
+      uint8_t p = s[i - k];
+      if ((p & 0xc0) == 0x80) continue;
+      covered = utf8_lead_len(p) > k;
+      break;
+    }
+    bad = !covered;
+  } else {
+    int L = utf8_lead_len(c);
+    if (L == 0 || i + L > n) {
+      bad = true;
+    } else {
+      uint8_t c1 = s[i + 1];
+      bad = (c1 & 0xc0) != 0x80;
+      if (L >= 3) bad |= (s[i + 2] & 0xc0) != 0x80;
+      if (L == 4) bad |= (s[i + 3] & 0xc0) != 0x80;
+      if (c == 0xe0) bad |= c1 < 0xa0;
+      if (c == 0xed) bad |= c1 > 0x9f;
+      if (c == 0xf0) bad |= c1 < 0x90;
+      if (c == 0xf4) bad |= c1 > 0x8f;
+    }
+  }
+  if (bad) report_err64(err, i, ORC_E_ARROW);
+}
+
+// Every row offset (and thereby every batch start) must sit on a character boundary.
+// base: per-batch byte base (nullptr for the dictionary: one "batch" with base 0 and stride n+1).
+extern "C" __global__ void __launch_bounds__(256) utf8_boundaries_kernel(const uint8_t* s, const int32_t* offsets, const unsigned long long* charbase,
+                                                                          uint64_t n_rows, uint32_t batch, const uint64_t* scalars, uint32_t n_idx,
+                                                                          unsigned long long* err) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  uint64_t b = i / batch;
+  uint64_t p = (charbase ? charbase[b] : 0) + (uint64_t)(uint32_t)offsets[b * ((uint64_t)batch + 1) + (i - b * batch)];
+  uint64_t n = scalars[n_idx];
+  if (p < n && (s[p] & 0xc0) == 0x80) report_err64(err, i, ORC_E_ARROW);
+}
+
+// Direct strings: the bytes consumed by all batches must exist in DATA (try_new: offsets past the buffer)
+extern "C" __global__ void string_data_check_kernel(const unsigned long long* chartot, const unsigned long long* charbase, uint32_t n_batches,
+                                                    const uint64_t* scalars, uint32_t data_len_idx, uint32_t batch, unsigned long long* err) {
+  uint32_t b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= n_batches) return;
+  if (charbase[b] + chartot[b] > scalars[data_len_idx]) report_err64(err, (uint64_t)b * batch, ORC_E_ARROW);
+}
+
+// ---- Decimal: zigzag varints -> i128 ----------------------------------------------------------------
+// pass 1: per 64-byte word a bitmask of terminator bytes (top bit clear) + popcount
+extern "C" __global__ void __launch_bounds__(256) varint_terms_kernel(const uint8_t* s, const uint64_t* scalars, uint32_t len_idx, uint64_t n_words,
+                                                                       unsigned long long* tmask, uint32_t* tpop) {
+  uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  uint64_t len = scalars[len_idx];
+  unsigned long long m = 0;
+  uint64_t base = w * 64;
+  for (int k = 0; k < 8; k++) {
+    uint64_t p = base + 8 * k;
+    if (p >= len) break;
+    uint64_t v = ~ld_u64(s + p) & 0x8080808080808080ull;
+    // gather bit 7 of each byte into 8 consecutive bits
+    uint64_t bits = (v * 0x0002040810204081ull) >> 56;
+    uint64_t rem = len - p;
+    if (rem < 8) bits &= (1ull << rem) - 1;
+    m |= bits << (8 * k);
+  }
+  tmask[w] = m;
+  tpop[w] = (uint32_t)__builtin_popcountll(m);
+}
+
+// pass 2: one thread per stream byte; terminators decode their varint into dense[k]
+extern "C" __global__ void __launch_bounds__(256) varint_decode128_kernel(const uint8_t* s, const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx,
+                                                                           const unsigned long long* tmask, const uint32_t* trank, __int128* dense,
+                                                                           uint64_t n_upper, unsigned long long* err) {
+  uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t len = scalars[len_idx];
+  if (len > n_upper) len = n_upper;
+  if (p >= len) return;
+  unsigned long long m = tmask[p >> 6];
+  uint32_t bit = p & 63;
+  if (!((m >> bit) & 1)) {
+    // an unterminated tail: the stream ends inside a varint
+    if (p == len - 1) {
+      uint64_t k = (uint64_t)trank[p >> 6] + __builtin_popcountll(m & ((1ull << bit) - 1));
+      uint64_t needed = scalars[needed_idx];
+      if (k < needed) {
+        uint64_t run = 1;
+        while (run <= 20 && run <= p && (s[p - run] & 0x80)) run++;
+        report_err64(err, k, run >= 20 ? ORC_E_VARINT : ORC_E_IO);
+      }
+    }
+    return;
+  }
+  uint64_t k = (uint64_t)trank[p >> 6] + __builtin_popcountll(m & ((1ull << bit) - 1));
+  uint64_t needed = scalars[needed_idx];
+  if (k >= needed) return;
+  uint64_t start = p;
+  while (start > 0 && p - start < 20 && (s[start - 1] & 0x80)) start--;
+  uint32_t nb = (uint32_t)(p - start + 1);
+  if (nb > 19) {  // byte index 19 has offset 133 >= 128: checked_shl fails (VarintTooLarge)
+    report_err64(err, k, ORC_E_VARINT);
+    return;
+  }
+  unsigned __int128 u = 0;
+  for (uint32_t i = 0; i < nb; i++) u |= (unsigned __int128)(s[start + i] & 0x7f) << (7 * i);
+  unsigned __int128 z = (u >> 1) ^ (unsigned __int128)(-(__int128)(u & 1));
+  dense[k] = (__int128)z;
+  // "not enough values": the last terminator knows how many values exist
+  if (p == len - 1 && k + 1 < needed) report_err64(err, k + 1, ORC_E_IO);
+}
+// empty DATA stream with values needed
+extern "C" __global__ void varint_empty_check_kernel(const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx, unsigned long long* err) {
+  if (threadIdx.x == 0 && scalars[len_idx] == 0 && scalars[needed_idx] > 0) report_err64(err, 0, ORC_E_IO);
+}
+
+// Decimal finish: null spacing + per-value scale repair (array_decoder/decimal.rs:138-166; release-build wrapping)
+extern "C" __global__ void __launch_bounds__(256) decimal_finish_kernel(const __int128* dense, const int32_t* scales, const unsigned long long* vbits,
+                                                                         const uint32_t* rank, __int128* out, uint64_t n_rows, uint32_t fixed_scale) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  uint64_t d = i;
+  bool valid = true;
+  if (vbits) {
+    unsigned long long word = vbits[i >> 6];
+    uint32_t bit = i & 63;
+    valid = (word >> bit) & 1;
+    d = (uint64_t)rank[i >> 6] + __builtin_popcountll(word & ((1ull << bit) - 1));
+  }
+  __int128 v = 0;
+  if (valid) {
+    v = dense[d];
+    uint32_t vs = (uint32_t)scales[d];
+    if (vs != fixed_scale) {
+      uint32_t k = fixed_scale < vs ? vs - fixed_scale : fixed_scale - vs;
+      unsigned __int128 f = 1;
+      for (uint32_t t = 0; t < k && t < 200; t++) f *= 10;
+      if (fixed_scale < vs) {
+        __int128 sf = (__int128)f;
+        if (sf != 0) v = v / sf;
+      } else {
+        v = (__int128)((unsigned __int128)v * f);
+      }
+    }
+  }
+  out[i] = v;
+}

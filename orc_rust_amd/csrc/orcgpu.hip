@@ -103,6 +103,7 @@ struct ChunkInfo {
   uint64_t src_off;  // offset of the chunk payload inside the stream
   uint32_t len;
   uint32_t original;
+  uint32_t plain_cap;  // bytes the chunk can expand to (exact for original and Snappy chunks)
 };
 
 struct StagedStream {
@@ -165,7 +166,8 @@ struct ColumnOut {
   int32_t ts_unit = 3;
   uint32_t precision = 0, scale = 0;
   bool has_present = false;
-  uint64_t values_off = 0, values_bytes = 0;      // in the result arena
+  uint64_t values_off = 0, values_bytes = 0;      // in the result arena (or the chars arena)
+  bool values_in_chars = false;                   // dictionary strings: values live in orcgpu_result::chars
   uint64_t offsets_off = 0;                       // strings: n_batches * (B+1) int32
   uint64_t validity_off = 0;                      // n_batches * words_per_batch u64
   std::vector<uint64_t> null_counts;              // host copy, per batch
@@ -182,6 +184,7 @@ struct orcgpu_result {
   uint64_t n_rows = 0;
   uint32_t batch = 8192, n_batches = 0, words_per_batch = 0;
   DevBuf arena;
+  DevBuf chars;  // dictionary -> Utf8 materialised value bytes (sized after the lengths are known)
   std::vector<ColumnOut> cols;
   int status = 0;
   uint32_t err_batch = 0, err_col = 0;
@@ -250,7 +253,15 @@ struct PlainStream {
   uint64_t scratch_off = ~0ull;  // scratch offset when decompressed
   uint64_t len_upper = 0;
   uint32_t len_idx = 0;          // scalar holding the actual plain length
+  uint32_t err_idx = 0;          // scalar holding a codec error flag (compressed streams)
   bool exists = false;
+};
+
+struct DecompStream {
+  const orcgpu_staged* stripe;
+  const StagedStream* st;
+  uint64_t scratch_off;
+  uint32_t len_idx, err_idx;
 };
 
 struct ColPlan {
@@ -266,6 +277,10 @@ struct ColPlan {
   uint32_t nullcount_off = 0; // index into the summary null-count array (per batch)
   uint32_t err_idx = 0;       // scalar: finisher error word
   int job_present = -1, job_data = -1, job_length = -1, job_secondary = -1;
+  bool is_dict = false;
+  uint32_t dictn_idx = 0, dicttotal_idx = 0, dicterr_idx = 0, utf8err_idx = 0;
+  uint64_t dictlens_off = 0, keys_off = 0;
+  uint64_t n_term_words = 0, tmask_off = 0, tpop_off = 0, trank_off = 0, ttiles_off = 0;
   uint64_t dense_off = 0, dense2_off = 0;  // dense temporaries in scratch
   // strings
   uint64_t lens_off = 0;       // spaced int32 lengths per row (scratch)
@@ -283,6 +298,8 @@ struct Plan {
   Bump scratch;
   std::vector<Bump> result_bump;
   uint64_t n_nullcount_slots = 0, n_chartot_slots = 0;
+  std::vector<int> pending_gathers;
+  std::vector<DecompStream> decomp;  // compressed streams to expand before anything else  // indices into cols: dictionary string columns waiting for their gather
   uint32_t new_scalar(uint64_t v) {
     scalars.push_back(v);
     return (uint32_t)scalars.size() - 1;
@@ -365,7 +382,22 @@ int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_sta
           st.framing_error = true;
           break;
         }
-        st.chunks.push_back(ChunkInfo{p + 3, len, h & 1});
+        uint32_t cap = (uint32_t)s->desc.block_size;
+        if (h & 1) {
+          cap = len;
+        } else if (d->compression == ORCGPU_COMP_SNAPPY) {
+          // Snappy blocks start with their uncompressed length (snap::raw::decompress_len, compression.rs:163-164)
+          uint64_t u = 0;
+          int shift = 0;
+          for (uint32_t k = 0; k < len && k < 5; k++) {
+            uint8_t c = in.ptr[p + 3 + k];
+            u |= (uint64_t)(c & 0x7f) << shift;
+            shift += 7;
+            if (!(c & 0x80)) break;
+          }
+          if (u <= (1ull << 31)) cap = (uint32_t)u;
+        }
+        st.chunks.push_back(ChunkInfo{p + 3, len, h & 1, cap});
         p += 3 + (uint64_t)len;
       }
       st.framed_len = p;
@@ -433,10 +465,12 @@ PlainStream plan_stream(Plan& P, orcgpu_staged* s, uint32_t col, int kind) {
     ps.len_idx = P.new_scalar(st->len);
   } else {
     uint64_t upper = 0;
-    for (auto& c : st->chunks) upper += c.original ? c.len : s->desc.block_size;
+    for (auto& c : st->chunks) upper += c.plain_cap;
     ps.len_upper = upper;
     ps.scratch_off = P.scratch.take(upper + ORC_PAD);
     ps.len_idx = P.new_scalar(0);  // written by the decompress finalize kernel
+    ps.err_idx = P.new_scalar(0);
+    P.decomp.push_back(DecompStream{s, st, ps.scratch_off, ps.len_idx, ps.err_idx});
   }
   return ps;
 }
@@ -470,6 +504,10 @@ hipError_t launch(void (*kernel)(Args...), uint64_t nthreads_or_blocks, bool is_
   hipLaunchKernelGGL(kernel, dim3((uint32_t)grid), dim3(bs), 0, st, args...);
   return hipGetLastError();
 }
+
+struct SummaryLayout {
+  uint64_t scalars_off = 0, jobs_off = 0, nullc_off = 0, chartot_off = 0, bytes = 0;
+};
 
 }  // namespace
 

@@ -164,3 +164,105 @@ def test_error_cases():
             for batch in (8192, 500):
                 res = G.gpu_decode(n, cols, streams, batch_size=batch)
                 G.assert_column_parity(res, 0, cols[0], streams, n, batch, what=(name, typ, batch))
+
+
+def test_strings_direct_and_dictionary():
+    STRING, BINARY, LENGTH, DICT = 7, 8, 2, 3
+    n = 30000
+    rng = np.random.default_rng(21)
+    present = (rng.random(n) >= 0.15).astype(np.uint8)
+    k = int(present.sum())
+    words = [b"AIR", b"FOB", b"MAIL", b"RAIL", b"REG AIR", b"SHIP", b"TRUCK", "héllo".encode(), "日本語".encode(), b"", "\U0001f600".encode()]
+    cols, streams = [], []
+    # direct strings with nulls
+    idx = rng.integers(0, len(words), k)
+    lens = np.array([len(words[i]) for i in idx], dtype=np.int64)
+    blob = b"".join(words[i] for i in idx)
+    cols.append(col(1, STRING))
+    streams += [(1, PRESENT, gen.boolean(present)), (1, LENGTH, gen.rle2(lens, signed=False)), (1, DATA, np.frombuffer(blob, dtype=np.uint8))]
+    # dictionary strings with nulls (keys unsigned RLE)
+    dwords = sorted(set(words))
+    dlens = np.array([len(w) for w in dwords], dtype=np.int64)
+    keys = rng.integers(0, len(dwords), k)
+    cols.append(col(2, STRING, enc=3, dictionary_size=len(dwords)))
+    streams += [(2, PRESENT, gen.boolean(present)), (2, DATA, gen.rle2(keys, signed=False)), (2, LENGTH, gen.rle2(dlens, signed=False)),
+                (2, DICT, np.frombuffer(b"".join(dwords), dtype=np.uint8))]
+    # dictionary without nulls, binary direct
+    keys2 = rng.integers(0, len(dwords), n)
+    cols.append(col(3, STRING, enc=3, dictionary_size=len(dwords)))
+    streams += [(3, DATA, gen.rle2(keys2, signed=False)), (3, LENGTH, gen.rle2(dlens, signed=False)), (3, DICT, np.frombuffer(b"".join(dwords), dtype=np.uint8))]
+    raw = rng.integers(0, 256, 5 * n, dtype=np.uint8)
+    cols.append(col(4, BINARY))
+    streams += [(4, LENGTH, gen.rle2(np.full(n, 5), signed=False)), (4, DATA, raw)]
+    for batch in (8192, 999):
+        res = G.gpu_decode(n, cols, streams, batch_size=batch)
+        for ci, c in enumerate(cols):
+            G.assert_column_parity(res, ci, c, streams, n, batch, what=("strings", ci, batch))
+    # error cases: key out of range, invalid UTF-8, truncated DATA
+    bad_keys = keys2.copy()
+    bad_keys[n // 2] = len(dwords)
+    c = [col(1, STRING, enc=3, dictionary_size=len(dwords))]
+    s = [(1, DATA, gen.rle2(bad_keys, signed=False)), (1, LENGTH, gen.rle2(dlens, signed=False)), (1, DICT, np.frombuffer(b"".join(dwords), dtype=np.uint8))]
+    res = G.gpu_decode(n, c, s)
+    assert res.status()[0] == O.ARROW
+    G.assert_column_parity(res, 0, c[0], s, n, 8192, what="bad key")
+    blob2 = bytearray(blob)
+    blob2[len(blob2) // 2] = 0xFF
+    c = [col(1, STRING)]
+    s = [(1, PRESENT, gen.boolean(present)), (1, LENGTH, gen.rle2(lens, signed=False)), (1, DATA, np.frombuffer(bytes(blob2), dtype=np.uint8))]
+    res = G.gpu_decode(n, c, s)
+    G.assert_column_parity(res, 0, c[0], s, n, 8192, what="bad utf8")
+    s = [(1, PRESENT, gen.boolean(present)), (1, LENGTH, gen.rle2(lens, signed=False)), (1, DATA, np.frombuffer(blob[: len(blob) // 3], dtype=np.uint8))]
+    res = G.gpu_decode(n, c, s)
+    G.assert_column_parity(res, 0, c[0], s, n, 8192, what="short data")
+
+
+def test_decimals():
+    DECIMAL = 14
+    n = 25000
+    rng = np.random.default_rng(33)
+    present = (rng.random(n) >= 0.1).astype(np.uint8)
+    k = int(present.sum())
+    vals = [int(x) for x in rng.integers(-10**15, 10**15, k)]
+    vals[0] = 10**30
+    vals[1] = -(10**36)
+    scales = rng.integers(0, 6, k)
+    cols = [col(1, DECIMAL, precision=38, scale=3)]
+    streams = [(1, PRESENT, gen.boolean(present)), (1, DATA, gen.varint128(vals)), (1, SECONDARY, gen.rle2(scales, signed=True))]
+    for batch in (8192, 1234):
+        res = G.gpu_decode(n, cols, streams, batch_size=batch)
+        G.assert_column_parity(res, 0, cols[0], streams, n, batch, what=("decimal", batch))
+    data = gen.varint128(vals)
+    streams2 = [(1, PRESENT, gen.boolean(present)), (1, DATA, data[: len(data) // 2]), (1, SECONDARY, gen.rle2(scales, signed=True))]
+    res = G.gpu_decode(n, cols, streams2)
+    G.assert_column_parity(res, 0, cols[0], streams2, n, 8192, what="decimal truncated")
+
+
+@pytest.mark.parametrize("kind", ["snappy", "lz4", "zlib", "zstd"])
+@pytest.mark.parametrize("block", [64, 4096, 262144])
+def test_compressed_streams(kind, block):
+    """Chunk framing + block codecs: runs and varints straddle chunk boundaries (32..64-byte chunks
+    as in the reference's fixtures, scripts/write.py:82-96), original and compressed chunks mix."""
+    STRING, LENGTH = 7, 2
+    n = 40000
+    rng = np.random.default_rng(block)
+    present = (rng.random(n) >= 0.1).astype(np.uint8)
+    k = int(present.sum())
+    cols, streams = [], []
+    for i, vals in enumerate((rng.integers(0, 1 << 40, k), np.arange(k) * 7, np.repeat(rng.integers(0, 50, k // 6 + 1), 6)[:k],
+                              rng.integers(0, 7, k))):
+        cid = i + 1
+        cols.append(col(cid, LONG))
+        streams.append((cid, PRESENT, gen.compress_stream(gen.boolean(present), kind, block)))
+        streams.append((cid, DATA, gen.compress_stream(gen.rle2(np.asarray(vals, dtype=np.int64), signed=True), kind, block)))
+    words = [b"AIR", b"FOB", b"MAIL", b"RAIL", b"REG AIR", b"SHIP", b"TRUCK"]
+    idx = rng.integers(0, len(words), n)
+    blob = b"".join(words[i] for i in idx)
+    lens = np.array([len(words[i]) for i in idx], dtype=np.int64)
+    cols.append(col(9, STRING))
+    streams.append((9, LENGTH, gen.compress_stream(gen.rle2(lens, signed=False), kind, block)))
+    streams.append((9, DATA, gen.compress_stream(np.frombuffer(blob, dtype=np.uint8), kind, block)))
+    res = G.gpu_decode(n, cols, streams, compression=kind, block_size=block)
+    assert res.status()[0] == 0, res.status()
+    for ci, c in enumerate(cols):
+        G.assert_column_parity(res, ci, c, streams, n, 8192, compression=kind, block_size=block, what=(kind, block, ci))
