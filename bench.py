@@ -35,7 +35,7 @@ STRIPE_ROWS = 8_388_608
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def build_workload(rows_total, stripe_rows):
+def build_workload(rows_total, stripe_rows, kind="mix"):
     from orc_rust_amd import gen
     stripes = []
     base = 0
@@ -43,15 +43,18 @@ def build_workload(rows_total, stripe_rows):
     row = 0
     while row < rows_total:
         n = min(stripe_rows, rows_total - row)
-        if s % 2 == 0:
+        if (kind == "mix" and s % 2 == 0) or kind == "direct":
             vals = (gen.splitmix64(1 + s, n) & np.uint64((1 << 40) - 1)).astype(np.int64)
-            kind = "direct"
+            skind = "direct"
+        elif kind == "arange":
+            vals = np.arange(row, row + n, dtype=np.int64)
+            skind = "delta-fixed"
         else:
             deltas = (gen.splitmix64(2 + s, n) % np.uint64(255)).astype(np.int64) + 1
             vals = np.cumsum(deltas) + base
-            kind = "delta"
+            skind = "delta"
         stream, stats = gen.rle2(vals, signed=True, aligned=True, stats=True)
-        stripes.append({"n": n, "stream": stream, "kind": kind, "stats": stats, "first": vals[:4].copy(), "last": int(vals[-1]),
+        stripes.append({"n": n, "stream": stream, "kind": skind, "stats": stats, "first": vals[:4].copy(), "last": int(vals[-1]),
                         "xor": int(np.bitwise_xor.reduce(vals.view(np.uint64))), "sum": int(vals.view(np.uint64).sum(dtype=np.uint64))})
         row += n
         s += 1
@@ -93,6 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=ROWS_TOTAL)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--kind", default="mix", choices=["mix", "direct", "delta", "arange"], help="mix = the headline 50/50 workload")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,7 +114,7 @@ def main():
 
     from orc_rust_amd import capi
     ctx = capi.Context(local_rank)
-    stripes = build_workload(args.rows, STRIPE_ROWS)
+    stripes = build_workload(args.rows, STRIPE_ROWS, args.kind)
     cols = [{"column_id": 1, "orc_type": 4, "encoding": 2}]
     staged = [ctx.stage(st["n"], [(1, 1, st["stream"])], cols) for st in stripes]
     stream_bytes = sum(s.nbytes() for s in staged)
@@ -176,7 +180,8 @@ def main():
         "metric": "decoded GB/s + Mrows/s into Arrow", "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int64", "data": "synthetic",
-        "config": {"workload": "C2: RLEv2 DIRECT(48-bit)/DELTA(8-bit) 50/50 Int64 column, %d rows, uncompressed, %d stripes" % (rows, len(stripes)),
+        "config": {"workload": "C2: RLEv2 DIRECT(48-bit)/DELTA(8-bit) 50/50 Int64 column, %d rows, uncompressed, %d stripes" % (rows, len(stripes))
+                   if args.kind == "mix" else "C2 variant '%s': Int64 column, %d rows, uncompressed, %d stripes" % (args.kind, rows, len(stripes)),
                    "rows_per_gpu": rows, "stripe_rows": STRIPE_ROWS, "batch_size": 8192, "parallelism": "stripe-shard x%d" % world},
         "mrows_per_s": round(total_rows / (dt / args.steps) / 1e6, 1),
         "stream_bytes_in": stream_bytes, "arrow_bytes_out": arrow_bytes,

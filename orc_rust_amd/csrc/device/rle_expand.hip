@@ -31,6 +31,8 @@ struct WaveLds {
   int64_t base[64];
   int64_t delta[64];
   unsigned long long bitmap[8];
+  uint64_t spos[64];    // run slots of this iteration: stream offset of the run header (~0 = empty)
+  uint32_t soi[64];     // ... and the output index of its first value
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -70,7 +72,37 @@ __device__ __forceinline__ void report(RleJob* j, uint64_t needed, uint64_t oi, 
   if (oi < needed) atomicMin(&j->err, ((unsigned long long)oi << 8) | code);
 }
 
-template <int CODEC>
+// One value of a random-access run (SHORT_REPEAT, DIRECT, fixed DELTA, v1 run, byte run / literal).
+__device__ __forceinline__ int64_t decode_b1(uint32_t type, uint32_t w, int64_t base, int64_t dlt, const uint8_t* pp, uint32_t idx,
+                                             bool is_signed, int nbits, bool& bad) {
+  int64_t v;
+  if (type == RT_SR || type == RT_B_RUN) {
+    v = base;
+  } else if (type == RT_DIRECT) {
+    uint64_t u = unpack_be(pp, idx, w);
+    v = is_signed ? zigzag_n(u, nbits) : trunc_n((int64_t)u, nbits);
+  } else if (type == RT_B_LIT) {
+    v = (int8_t)pp[idx];
+  } else if (type == RT_DELTA) {  // fixed delta (delta.rs:84-93)
+    bool add = dlt > 0;
+    int64_t mag = dlt < 0 ? (int64_t)(0 - (uint64_t)dlt) : dlt;
+    uint64_t step = (uint64_t)idx * (uint64_t)mag;
+    v = add ? (int64_t)((uint64_t)base + step) : (int64_t)((uint64_t)base - step);
+    if (idx) {
+      int64_t prev = add ? (int64_t)((uint64_t)v - (uint64_t)mag) : (int64_t)((uint64_t)v + (uint64_t)mag);
+      bad |= (add ? add_ovf(prev, mag, v) : sub_ovf(prev, mag, v)) || !in_range_n(v, nbits);
+    }
+  } else {  // RT_V1_RUN (rle_v1.rs:102-132): checked add/sub of |delta| in N
+    v = (int64_t)((uint64_t)base + (uint64_t)((int64_t)idx * dlt));
+    if (idx) {
+      int64_t prev = (int64_t)((uint64_t)v - (uint64_t)dlt);
+      bad |= add_ovf(prev, dlt, v) || !in_range_n(v, nbits);
+    }
+  }
+  return v;
+}
+
+template <int CODEC, int OB>
 __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, const uint64_t* scalars, uint32_t lg, WaveLds& L,
                                              uint32_t lane) {
   const uint8_t* data = j->data;
@@ -78,8 +110,8 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
   const uint64_t len = scalars[j->len_idx];
   const uint64_t needed = scalars[j->needed_idx];
   const bool is_signed = j->is_signed;
-  const int nbits = j->nbits;
-  const uint32_t ob = j->out_bytes;
+  constexpr int nbits = OB * 8;   // the reference's NInt width always equals the Arrow value width
+  constexpr uint32_t ob = OB;
   const uint32_t G = j->group_size;
   const uint32_t eof_code = CODEC == CODEC_BYTE ? ORC_E_IO : ORC_E_OUT_OF_SPEC;
 
@@ -99,7 +131,33 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
   }
   bool clean = true;  // no failing run seen by this lane
 
-  while (__ballot(active)) {
+  // Lane l < G owns block l of the group and walks its run chain; per iteration it hands out up to
+  // K = 64 / G consecutive runs into "slots" l*K .. l*K+K-1, then every lane parses ONE slot in full.
+  // G = 64: one run per block per iteration; G = 1 (streams that expand a lot, e.g. fixed DELTA):
+  // 64 consecutive runs of the single block are expanded together.
+  const uint32_t K = 64u / G;
+  for (;;) {
+    L.spos[lane] = ~0ull;
+    wave_sync();
+    if (active) {
+      uint64_t p = pos, o = oi;
+      for (uint32_t k = 0; k < K && p < end && o < needed; k++) {
+        RunHdr hh;
+        run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, hh);
+        L.spos[lane * K + k] = p;
+        L.soi[lane * K + k] = (uint32_t)o;
+        if (hh.err) clean = false;
+        p += hh.size;
+        o += hh.n;
+      }
+      pos = p;
+      oi = o;
+      active = clean && pos < end && oi < needed;
+    }
+    wave_sync();
+    const uint64_t sp = L.spos[lane];
+    const bool has = sp != ~0ull;
+    if (!__ballot(has)) break;
     RunHdr h;
     h.n = 0;
     h.size = 0;
@@ -107,23 +165,23 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
     h.type = 0;
     bool is_b2 = false;
     uint32_t cnt = 0;
-    if (active) {
-      run_parse<CODEC, true>(data + pos, len - pos, is_signed, nbits, h);
+    if (has) {
+      const uint64_t soi = L.soi[lane];
+      run_parse<CODEC, true>(data + sp, len - sp, is_signed, nbits, h);
       if (h.err) {
-        report(j, needed, oi, h.err);
-        clean = false;
+        report(j, needed, soi, h.err);
       } else {
         is_b2 = (h.type == RT_DELTA && h.width != 0) || h.type == RT_PATCHED || h.type == RT_V1_LIT;
         cnt = is_b2 ? 0 : h.n;
       }
       L.meta[lane] = h.type | (h.width << 8) | (h.n << 16);
-      L.oidx[lane] = (uint32_t)oi;
-      L.pay[lane] = pos + h.payload;
+      L.oidx[lane] = (uint32_t)soi;
+      L.pay[lane] = sp + h.payload;
       L.base[lane] = h.base;
       L.delta[lane] = h.delta;
       if (CODEC == CODEC_RLE2 && h.type == RT_PATCHED) {
         L.meta2[lane] = h.pw | (h.pl << 8) | (h.cw << 16);
-        L.pay2[lane] = pos + h.patch_off;
+        L.pay2[lane] = sp + h.patch_off;
       }
     }
     uint32_t incl = wave_incl_scan_u32(cnt, lane);
@@ -133,66 +191,59 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
     wave_sync();
 
     // ---- B1: value-parallel expansion of the random-access runs -----------------------------
-    for (uint32_t q0 = 0; q0 < T; q0 += 64) {
-      // run containing q0 (wave uniform)
-      uint32_t lo = 0, hi = 64;
-      while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (L.start[mid] <= q0) lo = mid;
-        else hi = mid;
-      }
-      uint32_t q = q0 + lane;
-      if (q < T) {
-        uint32_t r = lo;
-        if (q >= L.start[r + 1]) {
-          uint32_t l2 = r, h2 = 64;
-          while (h2 - l2 > 1) {
-            uint32_t mid = (l2 + h2) >> 1;
-            if (L.start[mid] <= q) l2 = mid;
-            else h2 = mid;
+    {
+      uint32_t cur = 0;  // run that contains q0 (wave uniform, only moves forward)
+      for (uint32_t q0 = 0; q0 < T;) {
+        while (L.start[cur + 1] <= q0) cur++;
+        const uint32_t rend = L.start[cur + 1];
+        if (rend - q0 >= 256) {
+          // fast path: 256 values of ONE run, 4 per lane, run parameters wave-uniform
+          const uint32_t m = L.meta[cur];
+          const uint32_t type = m & 0xff, w = (m >> 8) & 0xff;
+          const int64_t base = L.base[cur], dlt = L.delta[cur];
+          const uint64_t o0 = L.oidx[cur];
+          const uint8_t* pp = data + L.pay[cur];
+          const uint32_t i0 = q0 - L.start[cur];
+          bool bad = false;
+          int64_t v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) v[u] = decode_b1(type, w, base, dlt, pp, i0 + u * 64 + lane, is_signed, nbits, bad);
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            uint64_t oo = o0 + i0 + u * 64 + lane;
+            if (oo < needed) store_val(out, ob, oo, v[u]);
           }
-          r = l2;
+          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
+          q0 += 256;
+          continue;
         }
-        uint32_t idx = q - L.start[r];
-        uint32_t m = L.meta[r];
-        uint32_t type = m & 0xff, w = (m >> 8) & 0xff;
-        int64_t base = L.base[r];
-        uint64_t o0 = L.oidx[r];
-        int64_t v;
-        bool bad = false;
-        if (type == RT_SR || type == RT_B_RUN) {
-          v = base;
-        } else if (type == RT_DIRECT) {
-          uint64_t u = unpack_be(data + L.pay[r], idx, w);
-          v = is_signed ? zigzag_n(u, nbits) : trunc_n((int64_t)u, nbits);
-        } else if (type == RT_B_LIT) {
-          v = (int8_t)data[L.pay[r] + idx];
-        } else if (type == RT_DELTA) {  // fixed delta (delta.rs:84-93)
-          int64_t db = L.delta[r];
-          bool add = db > 0;
-          int64_t mag = db < 0 ? (int64_t)(0 - (uint64_t)db) : db;
-          uint64_t step = (uint64_t)idx * (uint64_t)mag;
-          v = add ? (int64_t)((uint64_t)base + step) : (int64_t)((uint64_t)base - step);
-          if (idx) {
-            int64_t prev = add ? (int64_t)((uint64_t)v - (uint64_t)mag) : (int64_t)((uint64_t)v + (uint64_t)mag);
-            bad = (add ? add_ovf(prev, mag, v) : sub_ovf(prev, mag, v)) || !in_range_n(v, nbits);
+        uint32_t q = q0 + lane;
+        if (q < T) {
+          uint32_t r = cur;
+          if (q >= rend) {
+            uint32_t l2 = r, h2 = 64;
+            while (h2 - l2 > 1) {
+              uint32_t mid = (l2 + h2) >> 1;
+              if (L.start[mid] <= q) l2 = mid;
+              else h2 = mid;
+            }
+            r = l2;
           }
-        } else {  // RT_V1_RUN (rle_v1.rs:102-132): checked add/sub of |delta| in N
-          int64_t d = L.delta[r];
-          v = (int64_t)((uint64_t)base + (uint64_t)((int64_t)idx * d));
-          if (idx) {
-            int64_t prev = (int64_t)((uint64_t)v - (uint64_t)d);
-            bad = add_ovf(prev, d, v) || !in_range_n(v, nbits);
-          }
+          uint32_t idx = q - L.start[r];
+          uint32_t m = L.meta[r];
+          uint64_t o0 = L.oidx[r];
+          bool bad = false;
+          int64_t v = decode_b1(m & 0xff, (m >> 8) & 0xff, L.base[r], L.delta[r], data + L.pay[r], idx, is_signed, nbits, bad);
+          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
+          uint64_t oo = o0 + idx;
+          if (oo < needed) store_val(out, ob, oo, v);
         }
-        if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
-        uint64_t oo = o0 + idx;
-        if (oo < needed) store_val(out, ob, oo, v);
+        q0 += 64;
       }
     }
 
     // ---- B2: runs with an internal dependency, one run at a time, whole wave ------------------
-    unsigned long long m2 = __ballot(active && is_b2);
+    unsigned long long m2 = __ballot(has && is_b2 && !h.err);
     while (m2) {
       uint32_t r = (uint32_t)__builtin_ctzll(m2);
       m2 &= m2 - 1;
@@ -213,19 +264,29 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
         if (lane == 1 && o0 + 1 < needed) store_val(out, ob, o0 + 1, v1);
         int64_t acc = v1;
         uint32_t nd = n - 2;
-        for (uint32_t c = 0; c < nd; c += 64) {
-          uint32_t i = c + lane;
-          bool valid = i < nd;
-          int64_t d = valid ? (int64_t)unpack_be(pp, i, w) : 0;
-          uint64_t s = wave_incl_scan_u64((uint64_t)d, lane);
-          int64_t v = add ? (int64_t)((uint64_t)acc + s) : (int64_t)((uint64_t)acc - s);
-          int64_t prev = add ? (int64_t)((uint64_t)v - (uint64_t)d) : (int64_t)((uint64_t)v + (uint64_t)d);
-          if (valid) {
-            bad |= (add ? add_ovf(prev, d, v) : sub_ovf(prev, d, v)) || !in_range_n(v, nbits);
-            uint64_t oo = o0 + 2 + i;
-            if (oo < needed) store_val(out, ob, oo, v);
+        for (uint32_t c = 0; c < nd; c += 256) {
+          // four 64-delta steps per trip: all loads are issued before the dependent prefix sums
+          int64_t dd[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            uint32_t i = c + u * 64 + lane;
+            dd[u] = i < nd ? (int64_t)unpack_be(pp, i, w) : 0;
           }
-          acc = __shfl(v, 63);
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            uint32_t i = c + u * 64 + lane;
+            bool valid = i < nd;
+            int64_t d = dd[u];
+            uint64_t s = wave_incl_scan_u64((uint64_t)d, lane);
+            int64_t v = add ? (int64_t)((uint64_t)acc + s) : (int64_t)((uint64_t)acc - s);
+            int64_t prev = add ? (int64_t)((uint64_t)v - (uint64_t)d) : (int64_t)((uint64_t)v + (uint64_t)d);
+            if (valid) {
+              bad |= (add ? add_ovf(prev, d, v) : sub_ovf(prev, d, v)) || !in_range_n(v, nbits);
+              uint64_t oo = o0 + 2 + i;
+              if (oo < needed) store_val(out, ob, oo, v);
+            }
+            acc = __shfl(v, 63);
+          }
         }
       } else if (CODEC == CODEC_RLE2 && type == RT_PATCHED) {
         uint32_t m2v = L.meta2[r];
@@ -310,12 +371,6 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
       }
     }
     wave_sync();
-
-    if (active) {
-      pos += h.size;
-      oi += h.n;
-      active = pos < end && oi < needed;
-    }
   }
   // clean end of stream before `needed` values: "not enough values to decode"
   if (tail_owner && clean && pos >= len) report(j, needed, oi, eof_code);
@@ -336,7 +391,16 @@ __device__ __forceinline__ void expand_entry(RleJob* jobs, int njobs, RleBlocks 
   RleJob* j = &jobs[lo];
   uint32_t lg = g - j->group0;
   if (lg >= j->ngroups) return;
-  expand_group<CODEC>(j, blk, scalars, lg, lds[wv], lane);
+  if (CODEC == CODEC_BYTE) {
+    expand_group<CODEC, 1>(j, blk, scalars, lg, lds[wv], lane);
+  } else {
+    // wave-uniform dispatch on the value width: the bodies are specialised at compile time
+    switch (j->out_bytes) {
+      case 8: expand_group<CODEC, 8>(j, blk, scalars, lg, lds[wv], lane); break;
+      case 4: expand_group<CODEC, 4>(j, blk, scalars, lg, lds[wv], lane); break;
+      default: expand_group<CODEC, 2>(j, blk, scalars, lg, lds[wv], lane); break;
+    }
+  }
 }
 
 extern "C" __global__ void __launch_bounds__(256) rle2_expand_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,

@@ -24,6 +24,8 @@ struct RleJob {
   uint8_t nbits;           // width of the reference's NInt (8 for byte RLE)
   uint8_t out_bytes;       // 1, 2, 4 or 8
   uint32_t first_bad;      // first block whose entry disagrees with its predecessor (verify round)
+  uint32_t stat_bad;       // verify round: number of inconsistent blocks (diagnostics)
+  uint32_t stat_repaired;  // repair kernel: blocks rewritten (diagnostics)
   unsigned long long err;  // min over (first value index of the failing run << 8 | ORC_E_*)
 };
 
@@ -34,4 +36,5 @@ struct RleBlocks {
   uint32_t* voff;       // exclusive prefix of nvals inside the block's scan tile
   uint32_t* tile_base;  // per tile: values before the tile (within the job)
   uint8_t* flags;       // 1 = strong: entry verified by the candidate search (or filled by a strong owner)
+  uint32_t* badmap;     // 1 bit per block: inconsistent at the verify round (zeroed every call)
 };

@@ -25,6 +25,11 @@
 #include "rle_kernels.h"
 #include "rle_parse.h"
 
+__device__ __forceinline__ void wave_sync_scan() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ const RleJob* find_job_by_block(const RleJob* jobs, int njobs, uint32_t b) {
   int lo = 0, hi = njobs - 1;
   while (lo < hi) {
@@ -82,58 +87,146 @@ __device__ __forceinline__ bool plausible_header(const uint8_t* data, uint64_t l
   return true;
 }
 
-// First verified full-run header inside block lb, or RLE_BLK when none is found.
+// Prefilter: bit i of the result = byte i of the 8-byte word `w` may start a full-run header
+// (`nx` = the same word shifted by one byte, i.e. the bytes that follow).
 template <int CODEC>
-__device__ __forceinline__ uint32_t find_candidate(const uint8_t* data, uint64_t len, uint32_t lb, uint32_t stride_guess, bool is_signed,
-                                                   int nbits) {
-  const uint64_t b0 = (uint64_t)lb * RLE_BLK;
-  const uint64_t bend = b0 + RLE_BLK < len ? b0 + RLE_BLK : len;
-  if (stride_guess < RLE_BLK && b0 + stride_guess < bend && plausible_header<CODEC>(data, len, b0 + stride_guess, is_signed, nbits))
-    return stride_guess;
-  int tries = 0;
-  for (uint64_t p = b0; p < bend; p += 8) {
-    uint64_t w = ld_u64(data + p);
-    uint64_t m;
-    if (CODEC == CODEC_RLE2) {
-      // byte i: low bit set (length bit 8), type != SHORT_REPEAT, and byte i+1 == 0xFF (length low byte)
-      uint64_t nx = ~ld_u64(data + p + 1);
-      uint64_t ff = (nx - 0x0101010101010101ull) & ~nx & 0x8080808080808080ull;  // bytes of the next word equal to 0xFF
-      m = ff & ((w & 0x0101010101010101ull) << 7) & ((w | (w << 1)) & 0x8080808080808080ull);
-    } else {
-      uint64_t x = w ^ 0x8080808080808080ull;  // header byte 0x80 = 128 literals
-      m = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
-    }
-    while (m) {
-      uint32_t i = (uint32_t)__builtin_ctzll(m) >> 3;
-      m &= m - 1;
-      uint64_t c = p + i;
-      if (c >= bend) break;
-      if (plausible_header<CODEC>(data, len, c, is_signed, nbits)) return (uint32_t)(c - b0);
-      if (++tries >= 6) return RLE_BLK;
-    }
+__device__ __forceinline__ uint32_t prefilter8(uint64_t w, uint64_t nx) {
+  uint64_t m;
+  if (CODEC == CODEC_RLE2) {
+    // low bit set (length bit 8), type != SHORT_REPEAT, and the next byte == 0xFF (length low byte)
+    uint64_t n = ~nx;
+    uint64_t ff = (n - 0x0101010101010101ull) & ~n & 0x8080808080808080ull;
+    m = ff & ((w & 0x0101010101010101ull) << 7) & ((w | (w << 1)) & 0x8080808080808080ull);
+  } else {
+    uint64_t x = w ^ 0x8080808080808080ull;  // header byte 0x80 = 128 literals
+    m = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
   }
-  return RLE_BLK;
+  return (uint32_t)(((m >> 7) * 0x0102040810204080ull) >> 56);  // gather bit 7 of every byte
 }
 
-// mode 0: guess; 1: relaxation round; 2: verify only; 3: strong blocks fill their pass-through blocks
+// Candidate search for the 64 blocks of one wavefront (lane <-> block).  Lanes whose stride guess
+// already verified skip it.  For every block that needs it, all 64 lanes read the block with
+// coalesced 8-byte loads and leave a 512-bit prefilter bitmap in LDS; the owning lane then
+// verifies the candidates in order.  Returns the verified entry (or RLE_BLK).
+template <int CODEC>
+__device__ __forceinline__ uint32_t wave_find_candidates(const uint8_t* data, uint64_t len, uint32_t lb, bool need, bool is_signed, int nbits,
+                                                         unsigned long long (*bm)[8], uint32_t lane) {
+  unsigned long long todo = __ballot(need);
+  uint32_t lb0 = lb - lane;  // first block of the wave (wave-uniform)
+  while (todo) {
+    uint32_t k = (uint32_t)__builtin_ctzll(todo);
+    todo &= todo - 1;
+    uint64_t p = (uint64_t)(lb0 + k) * RLE_BLK + lane * 8;
+    uint32_t bits = 0;
+    if (p < len) {
+      uint64_t w = ld_u64(data + p), nx = ld_u64(data + p + 1);
+      bits = prefilter8<CODEC>(w, nx);
+      uint64_t rem = len - p;
+      if (rem < 8) bits &= (1u << rem) - 1;
+    }
+    reinterpret_cast<uint8_t*>(bm[k])[lane] = (uint8_t)bits;
+  }
+  wave_sync_scan();
+  uint32_t found = RLE_BLK;
+  if (need) {
+    const uint64_t b0 = (uint64_t)lb * RLE_BLK;
+    int tries = 0;
+    for (int wi = 0; wi < 8 && found == RLE_BLK && tries < 6; wi++) {
+      unsigned long long m = bm[lane][wi];
+      while (m && tries < 6) {
+        uint32_t i = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        uint64_t c = b0 + wi * 64 + i;
+        tries++;
+        if (plausible_header<CODEC>(data, len, c, is_signed, nbits)) {
+          found = (uint32_t)(c - b0);
+          break;
+        }
+      }
+    }
+  }
+  wave_sync_scan();
+  return found;
+}
+
+// mode 0: guess; 1: relaxation round; 2: verify only; 3: strong blocks fill their pass-through blocks.
+// Every wavefront covers 64 consecutive blocks of ONE stream (block ranges are RLE_TILE aligned).
 extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
                                                                    uint32_t total_blocks, int mode) {
+  __shared__ unsigned long long bitmaps[4][64][8];
   uint32_t b = blockIdx.x * 256u + threadIdx.x;
-  if (b >= total_blocks) return;
-  RleJob* j = const_cast<RleJob*>(find_job_by_block(jobs, njobs, b));
+  uint32_t lane = threadIdx.x & 63;
+  uint32_t bw = b - lane;  // first block of this wavefront
+  if (bw >= total_blocks) return;
+  RleJob* j = const_cast<RleJob*>(find_job_by_block(jobs, njobs, bw));
   uint32_t lb = b - j->block0;
-  if (lb >= j->nblocks) return;
   uint64_t len = scalars[j->len_idx];
-  if ((uint64_t)lb * RLE_BLK >= len && lb != 0) {
-    if (mode == 0) {
+  bool in_job = lb < j->nblocks;
+  bool live = in_job && ((uint64_t)lb * RLE_BLK < len || lb == 0);
+  const uint8_t* data = j->data;
+  if (mode == 0) {
+    uint32_t want = 0, strong = 0;
+    bool need = false;
+    if (live) {
+      if (lb == 0) {
+        strong = 1;
+      } else {
+        // stride guess from the stream's first run: exact for streams of equal-sized runs
+        RunHdr h;
+        if (j->codec == CODEC_RLE2) run_parse<CODEC_RLE2, false>(data, len, j->is_signed, j->nbits, h);
+        else if (j->codec == CODEC_RLE1) run_parse<CODEC_RLE1, false>(data, len, j->is_signed, j->nbits, h);
+        else run_parse<CODEC_BYTE, false>(data, len, false, 8, h);
+        uint32_t s0 = h.size ? h.size : 1;
+        uint32_t r = (uint32_t)(((uint64_t)lb * RLE_BLK) % s0);
+        uint32_t sg = r ? s0 - r : 0;
+        uint64_t gp = (uint64_t)lb * RLE_BLK + sg;  // guessed position of the next header (maybe in a later block)
+        bool ok = false;
+        if (gp < len) {
+          if (j->codec == CODEC_RLE2) ok = plausible_header<CODEC_RLE2>(data, len, gp, j->is_signed, j->nbits);
+          else if (j->codec == CODEC_RLE1) ok = plausible_header<CODEC_RLE1>(data, len, gp, j->is_signed, j->nbits);
+          else ok = plausible_header<CODEC_BYTE>(data, len, gp, false, 8);
+        }
+        if (ok) {
+          want = sg;  // >= RLE_BLK: this block lies inside a run (pass-through)
+          strong = 1;
+        } else {
+          need = true;
+        }
+      }
+    }
+    if (__ballot(need)) {
+      uint32_t cand;
+      unsigned long long(*bm)[8] = bitmaps[threadIdx.x >> 6];
+      if (j->codec == CODEC_RLE2) cand = wave_find_candidates<CODEC_RLE2>(data, len, lb, need, j->is_signed, j->nbits, bm, lane);
+      else if (j->codec == CODEC_RLE1) cand = wave_find_candidates<CODEC_RLE1>(data, len, lb, need, j->is_signed, j->nbits, bm, lane);
+      else cand = wave_find_candidates<CODEC_BYTE>(data, len, lb, need, false, 8, bm, lane);
+      if (need && cand < RLE_BLK) {
+        want = cand;
+        strong = 1;
+      }
+    }
+    if (!in_job) return;
+    if (!live) {
       blk.entry[b] = RLE_BLK;
       blk.exit_[b] = 0;
       blk.nvals[b] = 0;
       blk.flags[b] = 0;
+      return;
     }
+    uint32_t ex, nv;
+    if (want >= RLE_BLK) {
+      ex = want - RLE_BLK;
+      nv = 0;
+    } else {
+      walk_dispatch(j, data, len, lb, want, &ex, &nv);
+    }
+    blk.entry[b] = want;
+    blk.exit_[b] = ex;
+    blk.nvals[b] = nv;
+    blk.flags[b] = (uint8_t)strong;
     return;
   }
-  const uint8_t* data = j->data;
+  if (!live) return;
   if (mode == 3) {
     // a strong block whose last run extends over whole following blocks owns them
     if (!blk.flags[b]) return;
@@ -148,37 +241,13 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
     }
     return;
   }
-  uint32_t want;
-  uint32_t strong = 0;
-  if (lb == 0) {
-    want = 0;
-    strong = 1;
-  } else if (mode == 0) {
-    // stride guess from the stream's first run, then the candidate search
-    RunHdr h;
-    if (j->codec == CODEC_RLE2) run_parse<CODEC_RLE2, false>(data, len, j->is_signed, j->nbits, h);
-    else if (j->codec == CODEC_RLE1) run_parse<CODEC_RLE1, false>(data, len, j->is_signed, j->nbits, h);
-    else run_parse<CODEC_BYTE, false>(data, len, false, 8, h);
-    uint32_t s0 = h.size ? h.size : 1;
-    uint32_t r = (uint32_t)(((uint64_t)lb * RLE_BLK) % s0);
-    uint32_t sg = r ? s0 - r : 0;
-    uint32_t cand;
-    if (j->codec == CODEC_RLE2) cand = find_candidate<CODEC_RLE2>(data, len, lb, sg, j->is_signed, j->nbits);
-    else if (j->codec == CODEC_RLE1) cand = find_candidate<CODEC_RLE1>(data, len, lb, sg, j->is_signed, j->nbits);
-    else cand = find_candidate<CODEC_BYTE>(data, len, lb, sg, false, 8);
-    if (cand < RLE_BLK) {
-      want = cand;
-      strong = 1;
-    } else {
-      want = 0;
-    }
-  } else {
-    if (mode == 1 && blk.flags[b]) return;  // strong blocks hold their entry
-    want = blk.exit_[b - 1];
-  }
-  if (mode != 0 && want == blk.entry[b]) return;
+  if (mode == 1 && (blk.flags[b] || lb == 0)) return;  // strong blocks hold their entry
+  uint32_t want = lb == 0 ? 0u : blk.exit_[b - 1];
+  if (want == blk.entry[b]) return;
   if (mode == 2) {
     atomicMin(&j->first_bad, lb);
+    atomicAdd(&j->stat_bad, 1u);
+    atomicOr(&blk.badmap[b >> 5], 1u << (b & 31));
     return;
   }
   uint32_t ex, nv;
@@ -191,7 +260,6 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
   blk.entry[b] = want;
   blk.exit_[b] = ex;
   blk.nvals[b] = nv;
-  if (mode == 0) blk.flags[b] = (uint8_t)strong;
 }
 
 // Repair of whatever the relaxation rounds left inconsistent (long runs of irregular size never
@@ -227,17 +295,26 @@ __device__ __forceinline__ void repair_chain(RleJob* j, const RleBlocks& blk, ui
     fill_from = lb;
     uint32_t want = (uint32_t)(pos - (uint64_t)lb * RLE_BLK);
     if (blk.entry[b0 + lb] == want) {
-      // consistent here: find the next inconsistent block, 64 at a time.  Everything read below
-      // was written by earlier launches (this kernel only ever writes blocks below `lb`).
+      // consistent here: the verify round left a bitmap of inconsistent blocks; find the next one
+      // after lb (64 words = 2048 blocks per step).  Blocks this kernel repaired lie below lb.
       uint32_t next = nb;
-      for (uint32_t s = lb + 1; s < nb; s += 64) {
-        uint32_t c = s + lane;
-        bool mism = false;
-        if (c < nb) mism = blk.exit_[b0 + c - 1] != blk.entry[b0 + c];
-        unsigned long long m = __ballot(mism);
-        if (m) {
-          next = s + (uint32_t)__builtin_ctzll(m);
-          break;
+      {
+        uint32_t g0 = b0 + lb + 1, g1 = b0 + nb;  // global block range to search
+        for (uint32_t wbase = g0 >> 5; wbase <= ((g1 - 1) >> 5) && g0 < g1; wbase += 64) {
+          uint32_t wi = wbase + lane;
+          uint32_t word = 0;
+          if (wi <= ((g1 - 1) >> 5)) {
+            word = blk.badmap[wi];
+            if (wi == (g0 >> 5)) word &= ~0u << (g0 & 31);
+          }
+          unsigned long long m = __ballot(word != 0);
+          if (m) {
+            uint32_t l = (uint32_t)__builtin_ctzll(m);
+            uint32_t wsel = __shfl(word, l);
+            uint32_t g = ((wbase + l) << 5) + (uint32_t)__builtin_ctz(wsel);
+            if (g < g1) next = g - b0;
+            break;
+          }
         }
       }
       if (next >= nb) return;
@@ -286,6 +363,7 @@ __device__ __forceinline__ void repair_chain(RleJob* j, const RleBlocks& blk, ui
           }
         }
       }
+      if (lane == 0) j->stat_repaired += first_fail;
       pos += (uint64_t)first_fail * s;
       uint64_t fb = pos / RLE_BLK;
       fill_from = fb < nb ? (uint32_t)fb : nb;
@@ -297,6 +375,7 @@ __device__ __forceinline__ void repair_chain(RleJob* j, const RleBlocks& blk, ui
         blk.entry[b0 + lb] = want;
         blk.exit_[b0 + lb] = ex;
         blk.nvals[b0 + lb] = nvv;
+        j->stat_repaired += 1;
       }
       ex = __shfl(ex, 0);
       pos = (uint64_t)(lb + 1) * RLE_BLK + ex;
