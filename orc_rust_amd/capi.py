@@ -62,7 +62,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    so = _build.build()
+    so = os.environ.get("ORCGPU_LIB") or _build.build()
     L = C.CDLL(so)
     L.orcgpu_open.restype = C.c_void_p
     L.orcgpu_open.argtypes = [C.c_int, C.c_void_p]

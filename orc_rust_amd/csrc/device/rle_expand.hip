@@ -21,6 +21,13 @@
 #include "rle_kernels.h"
 #include "rle_parse.h"
 
+#ifndef ORC_FAST512
+#define ORC_FAST512 0
+#endif
+#ifndef ORC_EXPAND_WAVES
+#define ORC_EXPAND_WAVES 4
+#endif
+
 struct WaveLds {
   uint32_t start[65];
   uint32_t meta[64];    // type | width << 8 | n << 16
@@ -31,6 +38,7 @@ struct WaveLds {
   int64_t base[64];
   int64_t delta[64];
   unsigned long long bitmap[8];
+  int64_t tile[576];    // 512 values + 1 pad per 8: varying-DELTA transpose (lane-major -> value-major)
   uint64_t spos[64];    // run slots of this iteration: stream offset of the run header (~0 = empty)
   uint32_t soi[64];     // ... and the output index of its first value
 };
@@ -196,8 +204,29 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
       for (uint32_t q0 = 0; q0 < T;) {
         while (L.start[cur + 1] <= q0) cur++;
         const uint32_t rend = L.start[cur + 1];
+        if (ORC_FAST512 && rend - q0 >= 512) {
+          // fast path: 512 values of ONE run, 8 per lane, run parameters wave-uniform
+          const uint32_t m = L.meta[cur];
+          const uint32_t type = m & 0xff, w = (m >> 8) & 0xff;
+          const int64_t base = L.base[cur], dlt = L.delta[cur];
+          const uint64_t o0 = L.oidx[cur];
+          const uint8_t* pp = data + L.pay[cur];
+          const uint32_t i0 = q0 - L.start[cur];
+          bool bad = false;
+          int64_t v[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) v[u] = decode_b1(type, w, base, dlt, pp, i0 + u * 64 + lane, is_signed, nbits, bad);
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            uint64_t oo = o0 + i0 + u * 64 + lane;
+            if (oo < needed) store_val(out, ob, oo, v[u]);
+          }
+          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
+          q0 += 512;
+          continue;
+        }
         if (rend - q0 >= 256) {
-          // fast path: 256 values of ONE run, 4 per lane, run parameters wave-uniform
+          // 256 values of ONE run, 4 per lane
           const uint32_t m = L.meta[cur];
           const uint32_t type = m & 0xff, w = (m >> 8) & 0xff;
           const int64_t base = L.base[cur], dlt = L.delta[cur];
@@ -262,32 +291,44 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
         bad = (add ? add_ovf(base, mag, v1) : sub_ovf(base, mag, v1)) || !in_range_n(v1, nbits);
         if (lane == 0 && o0 < needed) store_val(out, ob, o0, base);
         if (lane == 1 && o0 + 1 < needed) store_val(out, ob, o0 + 1, v1);
-        int64_t acc = v1;
-        uint32_t nd = n - 2;
-        for (uint32_t c = 0; c < nd; c += 256) {
-          // four 64-delta steps per trip: all loads are issued before the dependent prefix sums
-          int64_t dd[4];
+        // n - 2 <= 510 packed deltas: lane l owns deltas 8l .. 8l+7 (for 8-bit deltas that is one
+        // 8-byte load), sums them locally, ONE wave scan over the lane totals gives every prefix,
+        // and an LDS transpose turns the lane-major results into coalesced stores.
+        const uint32_t nd = n - 2;
+        int64_t dl[8];
+        uint64_t run = 0;
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            uint32_t i = c + u * 64 + lane;
-            dd[u] = i < nd ? (int64_t)unpack_be(pp, i, w) : 0;
-          }
+        for (int k = 0; k < 8; k++) {
+          uint32_t i = lane * 8 + k;
+          dl[k] = i < nd ? (int64_t)unpack_be(pp, i, w) : 0;
+        }
+        uint64_t pre[8];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            uint32_t i = c + u * 64 + lane;
-            bool valid = i < nd;
-            int64_t d = dd[u];
-            uint64_t s = wave_incl_scan_u64((uint64_t)d, lane);
-            int64_t v = add ? (int64_t)((uint64_t)acc + s) : (int64_t)((uint64_t)acc - s);
-            int64_t prev = add ? (int64_t)((uint64_t)v - (uint64_t)d) : (int64_t)((uint64_t)v + (uint64_t)d);
-            if (valid) {
-              bad |= (add ? add_ovf(prev, d, v) : sub_ovf(prev, d, v)) || !in_range_n(v, nbits);
-              uint64_t oo = o0 + 2 + i;
-              if (oo < needed) store_val(out, ob, oo, v);
-            }
-            acc = __shfl(v, 63);
+        for (int k = 0; k < 8; k++) {
+          run += (uint64_t)dl[k];
+          pre[k] = run;
+        }
+        uint64_t incl = wave_incl_scan_u64(run, lane);
+        uint64_t excl = incl - run;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          uint32_t i = lane * 8 + k;
+          uint64_t sfx = excl + pre[k];
+          int64_t v = add ? (int64_t)((uint64_t)v1 + sfx) : (int64_t)((uint64_t)v1 - sfx);
+          int64_t prev = add ? (int64_t)((uint64_t)v - (uint64_t)dl[k]) : (int64_t)((uint64_t)v + (uint64_t)dl[k]);
+          if (i < nd) bad |= (add ? add_ovf(prev, dl[k], v) : sub_ovf(prev, dl[k], v)) || !in_range_n(v, nbits);
+          L.tile[i + (i >> 3)] = v;
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          uint32_t i = k * 64 + lane;
+          if (i < nd) {
+            uint64_t oo = o0 + 2 + i;
+            if (oo < needed) store_val(out, ob, oo, L.tile[i + (i >> 3)]);
           }
         }
+        wave_sync();
       } else if (CODEC == CODEC_RLE2 && type == RT_PATCHED) {
         uint32_t m2v = L.meta2[r];
         uint32_t pw = m2v & 0xff, pl = (m2v >> 8) & 0xff, cw = m2v >> 16;
@@ -403,7 +444,7 @@ __device__ __forceinline__ void expand_entry(RleJob* jobs, int njobs, RleBlocks 
   }
 }
 
-extern "C" __global__ void __launch_bounds__(256) rle2_expand_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
+extern "C" __global__ void __launch_bounds__(256, ORC_EXPAND_WAVES) rle2_expand_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
                                                                       uint32_t total_groups) {
   expand_entry<CODEC_RLE2>(jobs, njobs, blk, scalars, total_groups);
 }

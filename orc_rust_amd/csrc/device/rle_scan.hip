@@ -66,10 +66,11 @@ __device__ __forceinline__ void walk_dispatch(const RleJob* j, const uint8_t* da
 
 // A "full run" header at p that is followed by `hops` more headers of the same kind.
 template <int CODEC>
-__device__ __forceinline__ bool plausible_header(const uint8_t* data, uint64_t len, uint64_t p, bool is_signed, int nbits) {
+__device__ __forceinline__ bool plausible_header(const uint8_t* data, uint64_t len, uint64_t p, bool is_signed, int nbits, uint32_t* size_out = nullptr) {
   RunHdr h;
   run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, h);
   if (h.err) return false;
+  if (size_out) *size_out = h.size;
   if (CODEC == CODEC_RLE2) {
     if (h.n != 512 || h.type == RT_SR) return false;
   } else {
@@ -114,17 +115,30 @@ __device__ __forceinline__ uint32_t wave_find_candidates(const uint8_t* data, ui
   unsigned long long todo = __ballot(need);
   uint32_t lb0 = lb - lane;  // first block of the wave (wave-uniform)
   while (todo) {
-    uint32_t k = (uint32_t)__builtin_ctzll(todo);
-    todo &= todo - 1;
-    uint64_t p = (uint64_t)(lb0 + k) * RLE_BLK + lane * 8;
-    uint32_t bits = 0;
-    if (p < len) {
-      uint64_t w = ld_u64(data + p), nx = ld_u64(data + p + 1);
-      bits = prefilter8<CODEC>(w, nx);
-      uint64_t rem = len - p;
-      if (rem < 8) bits &= (1u << rem) - 1;
+    // four blocks per trip: all loads are issued before any of them is consumed
+    uint32_t kk[4];
+    uint64_t w[4], nx[4], pp[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      kk[u] = todo ? (uint32_t)__builtin_ctzll(todo) : 64u;
+      if (todo) todo &= todo - 1;
+      pp[u] = (uint64_t)(lb0 + kk[u]) * RLE_BLK + lane * 8;
+      bool in = kk[u] < 64 && pp[u] < len;
+      w[u] = in ? ld_u64(data + pp[u]) : 0;
+      nx[u] = in ? ld_u64(data + pp[u] + 1) : 0;
     }
-    reinterpret_cast<uint8_t*>(bm[k])[lane] = (uint8_t)bits;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (kk[u] < 64) {
+        uint32_t bits = 0;
+        if (pp[u] < len) {
+          bits = prefilter8<CODEC>(w[u], nx[u]);
+          uint64_t rem = len - pp[u];
+          if (rem < 8) bits &= (1u << rem) - 1;
+        }
+        reinterpret_cast<uint8_t*>(bm[kk[u]])[lane] = (uint8_t)bits;
+      }
+    }
   }
   wave_sync_scan();
   uint32_t found = RLE_BLK;
@@ -147,6 +161,18 @@ __device__ __forceinline__ uint32_t wave_find_candidates(const uint8_t* data, ui
   }
   wave_sync_scan();
   return found;
+}
+
+// Does the run chain that starts at `from` have a header exactly at `target` (> from)?
+template <int CODEC>
+__device__ __forceinline__ bool chain_hits(const uint8_t* data, uint64_t len, uint64_t from, uint64_t target, bool is_signed, int nbits) {
+  uint64_t p = from;
+  while (p < target && p < len) {
+    RunHdr h;
+    run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, h);
+    p += h.size;
+  }
+  return p == target;
 }
 
 // mode 0: guess; 1: relaxation round; 2: verify only; 3: strong blocks fill their pass-through blocks.
@@ -179,15 +205,21 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
         uint32_t s0 = h.size ? h.size : 1;
         uint32_t r = (uint32_t)(((uint64_t)lb * RLE_BLK) % s0);
         uint32_t sg = r ? s0 - r : 0;
-        uint64_t gp = (uint64_t)lb * RLE_BLK + sg;  // guessed position of the next header (maybe in a later block)
+        uint64_t gp = (uint64_t)lb * RLE_BLK + sg;  // guessed position of the first header at or after the block start
+        // Accept the guess only if the run BEFORE it is a verified full run of exactly s0 bytes that
+        // starts before this block: then [gp - s0, gp) holds no other header and gp is the block's
+        // first header (sg < RLE_BLK) or the block lies inside that run (sg >= RLE_BLK).
         bool ok = false;
-        if (gp < len) {
-          if (j->codec == CODEC_RLE2) ok = plausible_header<CODEC_RLE2>(data, len, gp, j->is_signed, j->nbits);
-          else if (j->codec == CODEC_RLE1) ok = plausible_header<CODEC_RLE1>(data, len, gp, j->is_signed, j->nbits);
-          else ok = plausible_header<CODEC_BYTE>(data, len, gp, false, 8);
+        if (gp >= s0 && gp <= len) {
+          uint32_t psize = 0;
+          uint64_t pp = gp - s0;
+          if (j->codec == CODEC_RLE2) ok = plausible_header<CODEC_RLE2>(data, len, pp, j->is_signed, j->nbits, &psize);
+          else if (j->codec == CODEC_RLE1) ok = plausible_header<CODEC_RLE1>(data, len, pp, j->is_signed, j->nbits, &psize);
+          else ok = plausible_header<CODEC_BYTE>(data, len, pp, false, 8, &psize);
+          ok = ok && psize == s0;
         }
         if (ok) {
-          want = sg;  // >= RLE_BLK: this block lies inside a run (pass-through)
+          want = sg;  // >= RLE_BLK: this block lies inside that run (pass-through)
           strong = 1;
         } else {
           need = true;
@@ -241,9 +273,25 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
     }
     return;
   }
-  if (mode == 1 && (blk.flags[b] || lb == 0)) return;  // strong blocks hold their entry
+  if (mode == 1 && lb == 0) return;
   uint32_t want = lb == 0 ? 0u : blk.exit_[b - 1];
   if (want == blk.entry[b]) return;
+  if (mode == 1 && blk.flags[b]) {
+    // A strong block ignores a weak predecessor (its exit may be garbage).  A STRONG predecessor's
+    // exit always lies on the true chain -- a false candidate only passes verification by hopping
+    // onto it -- so when the two disagree this block keeps its entry only if its own chain
+    // reaches the predecessor's header exactly (then the predecessor skipped runs, not us).
+    if (!blk.flags[b - 1]) return;
+    uint32_t e = blk.entry[b];
+    if (e < want && e < RLE_BLK) {
+      uint64_t from = (uint64_t)lb * RLE_BLK + e, target = (uint64_t)lb * RLE_BLK + want;
+      bool hits;
+      if (j->codec == CODEC_RLE2) hits = chain_hits<CODEC_RLE2>(data, len, from, target, j->is_signed, j->nbits);
+      else if (j->codec == CODEC_RLE1) hits = chain_hits<CODEC_RLE1>(data, len, from, target, j->is_signed, j->nbits);
+      else hits = chain_hits<CODEC_BYTE>(data, len, from, target, false, 8);
+      if (hits) return;
+    }
+  }
   if (mode == 2) {
     atomicMin(&j->first_bad, lb);
     atomicAdd(&j->stat_bad, 1u);
