@@ -175,6 +175,24 @@ __device__ __forceinline__ bool chain_hits(const uint8_t* data, uint64_t len, ui
   return p == target;
 }
 
+// Warm-up walk for blocks without a verified header: start RLE_WARMUP blocks earlier (offset 0 of
+// that block, or the true stream start) and hop forward.  A chain started at a wrong position
+// merges with the true chain after a few true-run lengths, so by the time it enters block lb it is
+// the true chain with high probability (short-run streams: P(miss) ~ (1 - 1/run_size)^hops).
+#define RLE_WARMUP 32u
+template <int CODEC>
+__device__ __forceinline__ uint32_t warmup_entry(const uint8_t* data, uint64_t len, uint32_t lb, bool is_signed, int nbits) {
+  uint32_t sb = lb > RLE_WARMUP ? lb - RLE_WARMUP : 0u;
+  uint64_t p = (uint64_t)sb * RLE_BLK, target = (uint64_t)lb * RLE_BLK;
+  for (int hops = 0; p < target && p < len && hops < 8192; hops++) {
+    RunHdr h;
+    run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, h);
+    p += h.size;
+  }
+  uint64_t e = p - target;
+  return p < target ? 0u : (e > 0x7fffffffull ? 0x7fffffffu : (uint32_t)e);
+}
+
 // mode 0: guess; 1: relaxation round; 2: verify only; 3: strong blocks fill their pass-through blocks.
 // Every wavefront covers 64 consecutive blocks of ONE stream (block ranges are RLE_TILE aligned).
 extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
@@ -235,7 +253,14 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
       if (need && cand < RLE_BLK) {
         want = cand;
         strong = 1;
+        need = false;
       }
+    }
+    if (need) {
+      // weak block: entry from a warm-up walk that started a few KiB earlier
+      if (j->codec == CODEC_RLE2) want = warmup_entry<CODEC_RLE2>(data, len, lb, j->is_signed, j->nbits);
+      else if (j->codec == CODEC_RLE1) want = warmup_entry<CODEC_RLE1>(data, len, lb, j->is_signed, j->nbits);
+      else want = warmup_entry<CODEC_BYTE>(data, len, lb, false, 8);
     }
     if (!in_job) return;
     if (!live) {
