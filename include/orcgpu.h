@@ -167,6 +167,29 @@ struct ArrowArray;
 int orcgpu_result_export_batch(orcgpu_ctx* ctx, const orcgpu_result* r, uint32_t batch, struct ArrowArray* out_array,
                                struct ArrowSchema* out_schema);
 
+/* ---- file reader: host-side mirror of ArrowReaderBuilder / ArrowReader ---------------------------------- */
+/* The container layer around the hot path, restated in C++ inside liborcgpu.so because it produces
+ * the kernel inputs: ChunkReader (src/reader/mod.rs:27-76), read_metadata (src/reader/metadata.rs:
+ * 180-247), Stripe::new (src/stripe.rs:127-182), ProjectionMask::named_roots (src/projection.rs:52-69),
+ * ArrowReaderBuilder::{try_new, with_batch_size, with_projection, with_file_byte_range,
+ * with_timestamp_precision, build} (src/arrow_reader.rs:70-231) and ArrowReader::{next,
+ * total_row_count} (:243-346).  Setters must be called before the first next_batch ("build"). */
+typedef struct orcgpu_reader orcgpu_reader;
+int orcgpu_reader_open_file(orcgpu_ctx* ctx, const char* path, orcgpu_reader** out);                 /* try_new(File)  */
+int orcgpu_reader_open_bytes(orcgpu_ctx* ctx, const uint8_t* data, uint64_t len, orcgpu_reader** out); /* try_new(Bytes) */
+void orcgpu_reader_close(orcgpu_reader* r);
+int orcgpu_reader_set_batch_size(orcgpu_reader* r, uint32_t batch_size);                             /* with_batch_size */
+int orcgpu_reader_set_projection(orcgpu_reader* r, const char* const* root_names, uint32_t n);       /* named_roots     */
+int orcgpu_reader_set_byte_range(orcgpu_reader* r, uint64_t start, uint64_t end);                    /* with_file_byte_range */
+int orcgpu_reader_set_timestamp_precision(orcgpu_reader* r, int arrow_target);                       /* ORCGPU_ARROW_TIMESTAMP_* */
+uint64_t orcgpu_reader_total_rows(const orcgpu_reader* r);                                           /* total_row_count */
+uint32_t orcgpu_reader_stripe_count(const orcgpu_reader* r);
+uint32_t orcgpu_reader_column_count(orcgpu_reader* r);                                               /* projected flat columns */
+const char* orcgpu_reader_column_name(orcgpu_reader* r, uint32_t i);
+/* ArrowReader::next: 0 = one RecordBatch exported (struct array, host memory), 1 = end of file,
+ * anything else = the OrcError status of the failing batch (the iterator then ends). */
+int orcgpu_reader_next_batch(orcgpu_reader* r, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+
 /* ---- timing hooks used by bench.py (HIP events on the context's own stream) ---------------------- */
 /* Milliseconds the device spent in the last orcgpu_decode_staged call, whole call and the RLE
  * expansion kernels alone (the dominant kernel), measured with hipEvents on the ctx stream. */

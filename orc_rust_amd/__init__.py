@@ -3,5 +3,6 @@ src/encoding + src/array_decoder hot path).  The compute path is hand-written HI
 csrc/, reached through the C ABI of include/orcgpu.h; this package is the thin Python binding
 used by the tests and the benchmark."""
 from . import capi  # noqa: F401
+from .arrow_reader import ArrowReader, ArrowReaderBuilder  # noqa: F401
 
-__all__ = ["capi"]
+__all__ = ["capi", "ArrowReader", "ArrowReaderBuilder"]

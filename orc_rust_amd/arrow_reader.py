@@ -1,0 +1,99 @@
+"""ArrowReaderBuilder / ArrowReader: the reference's reader API (src/arrow_reader.rs:39-347) over the
+C++ host layer inside liborcgpu.so.  Pure plumbing: every call forwards to the C ABI
+(`orcgpu_reader_*`), batches arrive through the Arrow C Data Interface.
+
+    reader = ArrowReaderBuilder.try_new("file.orc").with_batch_size(8192).with_projection(["a", "b"]).build()
+    for batch in reader: ...            # pyarrow.RecordBatch, like `impl Iterator<Item = Result<RecordBatch>>`
+"""
+import ctypes as C
+
+from . import capi
+
+DEFAULT_BATCH_SIZE = 8192  # arrow_reader.rs:37
+
+
+class ArrowReaderBuilder:
+    def __init__(self, ctx, handle, keep=None):
+        self._ctx, self._h, self._keep = ctx, handle, keep
+
+    @classmethod
+    def try_new(cls, source, ctx=None):
+        """source: a path (`File`) or a bytes object (`Bytes`), the two ChunkReader impls of reader/mod.rs:48-76."""
+        ctx = ctx or capi.Context(0)
+        out = C.c_void_p()
+        if isinstance(source, (bytes, bytearray)):
+            data = bytes(source)
+            ctx._check(ctx.L.orcgpu_reader_open_bytes(ctx.h, data, len(data), C.byref(out)))
+            return cls(ctx, out.value, data)
+        ctx._check(ctx.L.orcgpu_reader_open_file(ctx.h, str(source).encode(), C.byref(out)))
+        return cls(ctx, out.value)
+
+    def with_batch_size(self, n):
+        self._ctx._check(self._ctx.L.orcgpu_reader_set_batch_size(self._h, n))
+        return self
+
+    def with_projection(self, root_names):
+        """ProjectionMask::named_roots (projection.rs:52-69)."""
+        arr = (C.c_char_p * len(root_names))(*[n.encode() for n in root_names])
+        self._ctx._check(self._ctx.L.orcgpu_reader_set_projection(self._h, arr, len(root_names)))
+        return self
+
+    def with_file_byte_range(self, start, end):
+        self._ctx._check(self._ctx.L.orcgpu_reader_set_byte_range(self._h, start, end))
+        return self
+
+    def with_timestamp_precision(self, unit):
+        """unit: 'us' or 'ns' (TimestampPrecision, schema.rs:31-38); 's'/'ms' as with_schema overrides."""
+        self._ctx._check(self._ctx.L.orcgpu_reader_set_timestamp_precision(self._h, {"s": 1, "ms": 2, "us": 3, "ns": 4}[unit]))
+        return self
+
+    def total_row_count(self):
+        return self._ctx.L.orcgpu_reader_total_rows(self._h)
+
+    def stripe_count(self):
+        return self._ctx.L.orcgpu_reader_stripe_count(self._h)
+
+    def build(self):
+        r = ArrowReader(self._ctx, self._h, self._keep)
+        self._h = None
+        return r
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._ctx.L.orcgpu_reader_close(self._h)
+
+
+class ArrowReader:
+    def __init__(self, ctx, handle, keep=None):
+        self._ctx, self._h, self._keep = ctx, handle, keep
+
+    def total_row_count(self):
+        return self._ctx.L.orcgpu_reader_total_rows(self._h)
+
+    def column_names(self):
+        n = self._ctx.L.orcgpu_reader_column_count(self._h)
+        return [self._ctx.L.orcgpu_reader_column_name(self._h, i).decode() for i in range(n)]
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        import pyarrow as pa
+        a = (C.c_uint8 * 80)()
+        s = (C.c_uint8 * 72)()
+        rc = self._ctx.L.orcgpu_reader_next_batch(self._h, C.addressof(a), C.addressof(s))
+        if rc == 1:
+            raise StopIteration
+        self._ctx._check(rc)
+        return pa.RecordBatch._import_from_c(C.addressof(a), C.addressof(s))
+
+    def close(self):
+        if self._h:
+            self._ctx.L.orcgpu_reader_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -21,6 +21,10 @@ EXPORTS = [
     "orcgpu_staged_bytes", "orcgpu_decode_staged", "orcgpu_stripe_decode", "orcgpu_result_free", "orcgpu_result_status",
     "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
     "orcgpu_result_copy_batch", "orcgpu_result_export_batch", "orcgpu_last_timing",
+    "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
+    "orcgpu_reader_set_projection", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision",
+    "orcgpu_reader_total_rows", "orcgpu_reader_stripe_count", "orcgpu_reader_column_count", "orcgpu_reader_column_name",
+    "orcgpu_reader_next_batch",
 ]
 
 
@@ -88,6 +92,22 @@ def load():
     L.orcgpu_result_copy_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orcgpu_result_export_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.orcgpu_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.orcgpu_reader_open_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.orcgpu_reader_open_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.orcgpu_reader_close.argtypes = [C.c_void_p]
+    L.orcgpu_reader_set_batch_size.argtypes = [C.c_void_p, C.c_uint32]
+    L.orcgpu_reader_set_projection.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32]
+    L.orcgpu_reader_set_byte_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    L.orcgpu_reader_set_timestamp_precision.argtypes = [C.c_void_p, C.c_int]
+    L.orcgpu_reader_total_rows.restype = C.c_uint64
+    L.orcgpu_reader_total_rows.argtypes = [C.c_void_p]
+    L.orcgpu_reader_stripe_count.restype = C.c_uint32
+    L.orcgpu_reader_stripe_count.argtypes = [C.c_void_p]
+    L.orcgpu_reader_column_count.restype = C.c_uint32
+    L.orcgpu_reader_column_count.argtypes = [C.c_void_p]
+    L.orcgpu_reader_column_name.restype = C.c_char_p
+    L.orcgpu_reader_column_name.argtypes = [C.c_void_p, C.c_uint32]
+    L.orcgpu_reader_next_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

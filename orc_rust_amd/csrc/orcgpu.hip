@@ -514,3 +514,4 @@ struct SummaryLayout {
 #include "orcgpu_ext.inc"
 #include "orcgpu_decode.inc"
 #include "orcgpu_export.inc"
+#include "orcgpu_reader.inc"
