@@ -225,6 +225,49 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           q0 += 512;
           continue;
         }
+        if (OB == 8 && rend - q0 >= 512 && (uint64_t)L.oidx[cur] + (q0 - L.start[cur]) + 512 <= needed) {
+          // 512 int64 values of ONE run: every lane produces PAIRS of consecutive values, so one
+          // 16-byte load feeds two values and one 16-byte store writes them (1 KiB per wave store)
+          const uint32_t m = L.meta[cur];
+          const uint32_t type = m & 0xff, w = (m >> 8) & 0xff;
+          const int64_t base = L.base[cur], dlt = L.delta[cur];
+          const uint64_t o0 = L.oidx[cur];
+          const uint8_t* pp = data + L.pay[cur];
+          const uint32_t i0 = q0 - L.start[cur];
+          bool bad = false;
+          int64_t va[4], vb[4];
+          if (type == RT_DIRECT) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              uint32_t idx = i0 + u * 128 + 2 * lane;
+              uint64_t bit = (uint64_t)idx * w;
+              uint64_t raw[2];
+              __builtin_memcpy(raw, pp + (bit >> 3), 16);
+              uint64_t hi = __builtin_bswap64(raw[0]), lo = __builtin_bswap64(raw[1]);
+              uint32_t sh = bit & 7, t = sh + w;
+              uint64_t a = (hi << sh) >> (64 - w);
+              uint64_t top = t < 64 ? ((hi << t) | (lo >> (64 - t))) : (lo << (t - 64));
+              uint64_t b = top >> (64 - w);
+              va[u] = is_signed ? zigzag_n(a, 64) : (int64_t)a;
+              vb[u] = is_signed ? zigzag_n(b, 64) : (int64_t)b;
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              uint32_t idx = i0 + u * 128 + 2 * lane;
+              va[u] = decode_b1(type, w, base, dlt, pp, idx, is_signed, nbits, bad);
+              vb[u] = decode_b1(type, w, base, dlt, pp, idx + 1, is_signed, nbits, bad);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            int64_t pr[2] = {va[u], vb[u]};
+            __builtin_memcpy((int64_t*)out + o0 + i0 + u * 128 + 2 * lane, pr, 16);
+          }
+          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
+          q0 += 512;
+          continue;
+        }
         if (rend - q0 >= 256) {
           // 256 values of ONE run, 4 per lane
           const uint32_t m = L.meta[cur];
@@ -297,10 +340,16 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
         const uint32_t nd = n - 2;
         int64_t dl[8];
         uint64_t run = 0;
+        if (w == 8) {
+          uint64_t raw = ld_u64(pp + lane * 8);  // 8 one-byte deltas in one load
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          uint32_t i = lane * 8 + k;
-          dl[k] = i < nd ? (int64_t)unpack_be(pp, i, w) : 0;
+          for (int k = 0; k < 8; k++) dl[k] = lane * 8 + k < nd ? (int64_t)((raw >> (8 * k)) & 0xff) : 0;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            uint32_t i = lane * 8 + k;
+            dl[k] = i < nd ? (int64_t)unpack_be(pp, i, w) : 0;
+          }
         }
         uint64_t pre[8];
 #pragma unroll
