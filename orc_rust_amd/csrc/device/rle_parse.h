@@ -109,6 +109,57 @@ __device__ __forceinline__ uint32_t varint_n(const uint8_t* p, uint64_t avail, i
   return t + 1;
 }
 
+// 24-byte window of the stream at a run header: all header fields (2-4 bytes + up to two varints)
+// are extracted from registers, so a header costs ONE memory latency instead of a chain of
+// dependent byte loads.
+struct Win24 {
+  uint64_t w0, w1, w2;
+};
+__device__ __forceinline__ Win24 ld_win24(const uint8_t* p) {
+  Win24 w;
+  w.w0 = ld_u64(p);
+  w.w1 = ld_u64(p + 8);
+  w.w2 = ld_u64(p + 16);
+  return w;
+}
+__device__ __forceinline__ uint32_t win_byte(const Win24& w, uint32_t i) {
+  uint64_t v = i < 8 ? w.w0 : (i < 16 ? w.w1 : w.w2);
+  return (uint32_t)(v >> (8 * (i & 7))) & 0xff;
+}
+// 8 bytes of the window starting at byte offset off (<= 16); bytes past the window read as 0
+__device__ __forceinline__ uint64_t win_u64(const Win24& w, uint32_t off) {
+  uint64_t a = off < 8 ? w.w0 : (off < 16 ? w.w1 : w.w2);
+  uint64_t b = off < 8 ? w.w1 : (off < 16 ? w.w2 : 0ull);
+  uint32_t sh = 8 * (off & 7);
+  return sh ? (a >> sh) | (b << (64 - sh)) : a;
+}
+// varint_n on a window: the varint starts at window byte `off` (off <= 12 so that 10 bytes are visible)
+__device__ __forceinline__ uint32_t varint_win(const Win24& w, uint32_t off, uint64_t avail, int nbits, uint64_t* out, uint32_t* err) {
+  uint64_t lo = win_u64(w, off), hi = win_u64(w, off + 8);
+  uint64_t tl = ~lo & 0x8080808080808080ull, th = ~hi & 0x8080808080808080ull;
+  uint32_t t;
+  if (tl) t = (uint32_t)(__builtin_ctzll(tl) >> 3);
+  else if (th) t = (uint32_t)(__builtin_ctzll(th) >> 3) + 8;
+  else t = 16;
+  uint32_t max_groups = (uint32_t)(nbits + 6) / 7;
+  uint32_t lim = avail < max_groups ? (uint32_t)avail : max_groups;
+  if (t >= lim) {
+    if (avail > max_groups) {
+      *err = ORC_E_VARINT;
+      return max_groups + 1;
+    }
+    return 0;
+  }
+  uint64_t v = 0;
+  for (uint32_t i = 0; i <= t; i++) {
+    uint64_t b = (i < 8 ? (lo >> (8 * i)) : (hi >> (8 * (i - 8)))) & 0x7f;
+    v |= b << (7 * i);
+  }
+  if (nbits < 64) v &= (1ull << nbits) - 1;
+  *out = v;
+  return t + 1;
+}
+
 // One parsed run.  `size` and `n` are what the block walk needs; the rest feeds expansion.
 struct RunHdr {
   uint32_t size;      // bytes of the whole run (header + payload); clamped to `avail` when truncated
@@ -126,7 +177,8 @@ struct RunHdr {
 // Parse the RLE v2 run whose header byte is p[0]; avail >= 1 bytes remain from p.
 template <bool FULL>
 __device__ __forceinline__ void rle2_parse(const uint8_t* p, uint64_t avail, bool is_signed, int nbits, RunHdr& h) {
-  uint32_t h0 = p[0];
+  const Win24 win = ld_win24(p);
+  uint32_t h0 = win_byte(win, 0);
   h.err = 0;
   h.type = h0 >> 6;
   h.base = 0;
@@ -140,7 +192,7 @@ __device__ __forceinline__ void rle2_parse(const uint8_t* p, uint64_t avail, boo
     if ((uint32_t)nbits < h.width) h.err = ORC_E_OUT_OF_SPEC;          // short_repeat.rs:46-52 (before any read)
     else if (h.size > avail) h.err = ORC_E_IO;
     if (FULL && !h.err) {
-      uint64_t v = ld_be64(p + 1) >> (64 - 8 * bw);
+      uint64_t v = __builtin_bswap64(win_u64(win, 1)) >> (64 - 8 * bw);
       h.base = is_signed ? zigzag_n(v, nbits) : trunc_n((int64_t)v, nbits);
     }
   } else if (h.type == RT_DIRECT) {
@@ -156,7 +208,7 @@ __device__ __forceinline__ void rle2_parse(const uint8_t* p, uint64_t avail, boo
       h.n = 0;
       h.size = 1;
     } else {
-      h.n = (((h0 & 1) << 8) | p[1]) + 1;
+      h.n = (((h0 & 1) << 8) | win_byte(win, 1)) + 1;
       h.size = 2 + ((h.n * w + 7) >> 3);
       if (h.size > avail) h.err = ORC_E_IO;
     }
@@ -168,8 +220,8 @@ __device__ __forceinline__ void rle2_parse(const uint8_t* p, uint64_t avail, boo
       h.n = 0;
       h.size = (uint32_t)avail;
     } else {
-      h.n = (((h0 & 1) << 8) | p[1]) + 1;
-      uint32_t b2 = p[2], b3 = p[3];
+      h.n = (((h0 & 1) << 8) | win_byte(win, 1)) + 1;
+      uint32_t b2 = win_byte(win, 2), b3 = win_byte(win, 3);
       uint32_t bw = ((b2 >> 5) & 7) + 1;
       h.pw = rle2_width(b2 & 31);
       h.pgw = ((b3 >> 5) & 7) + 1;
@@ -189,7 +241,7 @@ __device__ __forceinline__ void rle2_parse(const uint8_t* p, uint64_t avail, boo
         h.err = ORC_E_OUT_OF_SPEC;                                       // patches[0] (index panic in the reference)
       }
       if (FULL && !h.err) {
-        uint64_t b = ld_be64(p + 4) >> (64 - 8 * bw);
+        uint64_t b = __builtin_bswap64(win_u64(win, 4)) >> (64 - 8 * bw);
         int64_t base;
         if (is_signed) {                                                 // signed_msb_decode (integer/util.rs:559-569)
           uint64_t m = 1ull << (bw * 8 - 1);
@@ -209,11 +261,11 @@ __device__ __forceinline__ void rle2_parse(const uint8_t* p, uint64_t avail, boo
       h.err = ORC_E_IO;
       h.size = (uint32_t)avail;
     } else {
-      uint32_t n = (((h0 & 1) << 8) | p[1]) + 1;
+      uint32_t n = (((h0 & 1) << 8) | win_byte(win, 1)) + 1;
       uint64_t ub = 0, ud = 0;
       uint32_t e1 = 0, e2 = 0;
-      uint32_t l1 = varint_n(p + 2, avail - 2, nbits, &ub, &e1);
-      uint32_t l2 = l1 ? varint_n(p + 2 + l1, avail - 2 - l1, 64, &ud, &e2) : 0;
+      uint32_t l1 = varint_win(win, 2, avail - 2, nbits, &ub, &e1);
+      uint32_t l2 = (l1 && !e1) ? varint_win(win, 2 + l1, avail - 2 - l1, 64, &ud, &e2) : 0;
       if (!l1 || (!e1 && !l2)) {
         h.err = ORC_E_IO;
       } else if (e1 || e2) {
@@ -245,7 +297,8 @@ __device__ __forceinline__ void rle2_parse(const uint8_t* p, uint64_t avail, boo
 // RLE v1 (rle_v1.rs:54-68, :90-132)
 template <bool FULL>
 __device__ __forceinline__ void rle1_parse(const uint8_t* p, uint64_t avail, bool is_signed, int nbits, RunHdr& h) {
-  int32_t h0 = (int8_t)p[0];
+  const Win24 win = ld_win24(p);
+  int32_t h0 = (int8_t)win_byte(win, 0);
   h.err = 0;
   h.base = 0;
   h.delta = 0;
@@ -258,14 +311,14 @@ __device__ __forceinline__ void rle1_parse(const uint8_t* p, uint64_t avail, boo
     } else {
       uint64_t ub = 0;
       uint32_t e = 0;
-      uint32_t l = varint_n(p + 2, avail - 2, nbits, &ub, &e);
+      uint32_t l = varint_win(win, 2, avail - 2, nbits, &ub, &e);
       if (!l) h.err = ORC_E_IO;
       else if (e) h.err = ORC_E_VARINT;
       h.size = 2 + l;
       h.payload = 2;
       if (FULL && !h.err) {
         h.base = is_signed ? zigzag_n(ub, nbits) : trunc_n((int64_t)ub, nbits);
-        h.delta = (int8_t)p[1];
+        h.delta = (int8_t)win_byte(win, 1);
       }
     }
   } else {
@@ -303,7 +356,8 @@ __device__ __forceinline__ void rle1_parse(const uint8_t* p, uint64_t avail, boo
 // byte RLE (byte.rs:228-247)
 template <bool FULL>
 __device__ __forceinline__ void byte_parse(const uint8_t* p, uint64_t avail, RunHdr& h) {
-  uint32_t h0 = p[0];
+  const uint64_t w0 = ld_u64(p);
+  uint32_t h0 = (uint32_t)w0 & 0xff;
   h.err = 0;
   h.width = 8;
   h.delta = 0;
@@ -314,7 +368,7 @@ __device__ __forceinline__ void byte_parse(const uint8_t* p, uint64_t avail, Run
     h.size = 2;
     h.base = 0;
     if (avail < 2) h.err = ORC_E_IO;
-    else if (FULL) h.base = (int8_t)p[1];
+    else if (FULL) h.base = (int8_t)((w0 >> 8) & 0xff);
   } else {
     h.type = RT_B_LIT;
     h.n = 0x100 - h0;

@@ -229,12 +229,27 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
         // first header (sg < RLE_BLK) or the block lies inside that run (sg >= RLE_BLK).
         bool ok = false;
         if (gp >= s0 && gp <= len) {
-          uint32_t psize = 0;
-          uint64_t pp = gp - s0;
-          if (j->codec == CODEC_RLE2) ok = plausible_header<CODEC_RLE2>(data, len, pp, j->is_signed, j->nbits, &psize);
-          else if (j->codec == CODEC_RLE1) ok = plausible_header<CODEC_RLE1>(data, len, pp, j->is_signed, j->nbits, &psize);
-          else ok = plausible_header<CODEC_BYTE>(data, len, pp, false, 8, &psize);
-          ok = ok && psize == s0;
+          // cheap screen first: the two header bytes at gp - s0 (and at gp) must equal the stream's
+          // first two bytes.  For sub-encodings whose size is a function of those bytes alone
+          // (DIRECT, byte RLE) that already proves a run of exactly s0 bytes; the others still get
+          // the chained check.
+          const uint32_t head2 = ld_u32(data) & 0xffffu;
+          const uint32_t a2 = ld_u32(data + gp - s0) & 0xffffu;
+          const uint32_t b2 = gp < len ? (ld_u32(data + gp) & 0xffffu) : head2;
+          const uint32_t mask2 = j->codec == CODEC_RLE2 ? 0xffffu : 0xffu;
+          if (((a2 ^ head2) & mask2) == 0 && ((b2 ^ head2) & mask2) == 0) {
+            const bool self_sized = (j->codec == CODEC_RLE2 && h.type == RT_DIRECT) || j->codec == CODEC_BYTE;
+            if (self_sized && !h.err) {
+              ok = true;
+            } else {
+              uint32_t psize = 0;
+              uint64_t pp = gp - s0;
+              if (j->codec == CODEC_RLE2) ok = plausible_header<CODEC_RLE2>(data, len, pp, j->is_signed, j->nbits, &psize);
+              else if (j->codec == CODEC_RLE1) ok = plausible_header<CODEC_RLE1>(data, len, pp, j->is_signed, j->nbits, &psize);
+              else ok = plausible_header<CODEC_BYTE>(data, len, pp, false, 8, &psize);
+              ok = ok && psize == s0;
+            }
+          }
         }
         if (ok) {
           want = sg;  // >= RLE_BLK: this block lies inside that run (pass-through)
@@ -256,8 +271,17 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
         need = false;
       }
     }
-    if (need) {
-      // weak block: entry from a warm-up walk that started a few KiB earlier
+    uint32_t head_size = 0;
+    if (__ballot(need)) {
+      RunHdr hh;
+      if (j->codec == CODEC_RLE2) run_parse<CODEC_RLE2, false>(data, len ? len : 1, j->is_signed, j->nbits, hh);
+      else if (j->codec == CODEC_RLE1) run_parse<CODEC_RLE1, false>(data, len ? len : 1, j->is_signed, j->nbits, hh);
+      else run_parse<CODEC_BYTE, false>(data, len ? len : 1, false, 8, hh);
+      head_size = hh.size;
+    }
+    if (need && head_size < RLE_BLK / 2) {
+      // weak block of a short-run stream: entry from a warm-up walk that started a few KiB earlier
+      // (in long-run streams a block without a header is filled in by the strong block before it)
       if (j->codec == CODEC_RLE2) want = warmup_entry<CODEC_RLE2>(data, len, lb, j->is_signed, j->nbits);
       else if (j->codec == CODEC_RLE1) want = warmup_entry<CODEC_RLE1>(data, len, lb, j->is_signed, j->nbits);
       else want = warmup_entry<CODEC_BYTE>(data, len, lb, false, 8);
@@ -352,6 +376,7 @@ __device__ __forceinline__ void repair_chain(RleJob* j, const RleBlocks& blk, ui
   const bool is_signed = j->is_signed;
   const int nbits = j->nbits;
   const uint32_t b0 = j->block0;
+  uint32_t long_streak = 0;
   uint32_t fill_from = j->first_bad;  // blocks below are final; [fill_from, block(pos)) are pass-through
   uint64_t pos = (uint64_t)fill_from * RLE_BLK + (fill_from == 0 ? 0u : blk.exit_[b0 + fill_from - 1]);
   for (;;) {
@@ -399,21 +424,28 @@ __device__ __forceinline__ void repair_chain(RleJob* j, const RleBlocks& blk, ui
     run_parse<CODEC, false>(data + pos, len - pos, is_signed, nbits, h0);
     const uint32_t s = h0.size;
     if (s >= RLE_BLK && !h0.err) {
-      // ---- stride speculation over 256 candidates ----
-      uint32_t first_fail = 256;
-      uint32_t nv[4];
-      for (int k = 0; k < 4; k++) {
-        uint64_t c = pos + (uint64_t)(k * 64 + lane) * s;
-        bool ok = false;
-        nv[k] = 0;
-        if (c < len) {
-          RunHdr h;
-          run_parse<CODEC, false>(data + c, len - c, is_signed, nbits, h);
-          ok = !h.err && h.size == s;
-          nv[k] = h.n;
+      // ---- long run: isolated damage is repaired one run at a time; after 8 long runs in a row
+      //      the walker switches to stride speculation over 256 candidates per memory round trip
+      uint32_t first_fail = 1;
+      uint32_t nv[4] = {h0.n, 0, 0, 0};
+      if (long_streak >= 8) {
+        first_fail = 256;
+        for (int k = 0; k < 4; k++) {
+          uint64_t c = pos + (uint64_t)(k * 64 + lane) * s;
+          bool ok = false;
+          nv[k] = 0;
+          if (c < len) {
+            RunHdr h;
+            run_parse<CODEC, false>(data + c, len - c, is_signed, nbits, h);
+            ok = !h.err && h.size == s;
+            nv[k] = h.n;
+          }
+          unsigned long long bad = __ballot(!ok);
+          if (bad && first_fail == 256) first_fail = k * 64 + (uint32_t)__builtin_ctzll(bad);
         }
-        unsigned long long bad = __ballot(!ok);
-        if (bad && first_fail == 256) first_fail = k * 64 + (uint32_t)__builtin_ctzll(bad);
+        if (first_fail < 16) long_streak = 0;
+      } else {
+        long_streak++;
       }
       // candidates [0, first_fail) are proven headers of size s >= RLE_BLK: one header per block
       for (int k = 0; k < 4; k++) {
@@ -453,6 +485,7 @@ __device__ __forceinline__ void repair_chain(RleJob* j, const RleBlocks& blk, ui
       ex = __shfl(ex, 0);
       pos = (uint64_t)(lb + 1) * RLE_BLK + ex;
       fill_from = lb + 1;
+      long_streak = 0;
     }
   }
 }
