@@ -40,6 +40,12 @@ __device__ __forceinline__ const RleJob* find_job_by_block(const RleJob* jobs, i
   return &jobs[lo];
 }
 
+// Walks are speculative until verified: a header that fails to parse is most likely not a header
+// at all (the chain started at a wrong byte), so the walk re-synchronises one byte further instead
+// of giving up.  On the TRUE chain a failing run ends the stream for the decoder anyway (the
+// expansion reports the error at that run and ignores what follows), so this costs nothing there.
+__device__ __forceinline__ uint32_t hop_bytes(const RunHdr& h) { return h.err ? 1u : h.size; }
+
 template <int CODEC>
 __device__ __forceinline__ void walk_block(const uint8_t* data, uint64_t len, uint32_t lb, uint32_t entry, bool is_signed,
                                            int nbits, uint32_t* exit_out, uint32_t* nvals_out) {
@@ -48,10 +54,10 @@ __device__ __forceinline__ void walk_block(const uint8_t* data, uint64_t len, ui
   uint64_t pos = (uint64_t)lb * RLE_BLK + entry;
   uint32_t nv = 0;
   while (pos < end) {
-    RunHdr h;
-    run_parse<CODEC, false>(data + pos, len - pos, is_signed, nbits, h);
-    nv += h.n;
-    pos += h.size;
+    uint32_t sz, n, err;
+    hop_parse<CODEC>(data + pos, len - pos, is_signed, nbits, sz, n, err);
+    nv += n;
+    pos += err ? 1u : sz;
   }
   *exit_out = pos > bend ? (uint32_t)(pos - bend) : 0u;
   *nvals_out = nv;
@@ -170,27 +176,9 @@ __device__ __forceinline__ bool chain_hits(const uint8_t* data, uint64_t len, ui
   while (p < target && p < len) {
     RunHdr h;
     run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, h);
-    p += h.size;
+    p += hop_bytes(h);
   }
   return p == target;
-}
-
-// Warm-up walk for blocks without a verified header: start RLE_WARMUP blocks earlier (offset 0 of
-// that block, or the true stream start) and hop forward.  A chain started at a wrong position
-// merges with the true chain after a few true-run lengths, so by the time it enters block lb it is
-// the true chain with high probability (short-run streams: P(miss) ~ (1 - 1/run_size)^hops).
-#define RLE_WARMUP 32u
-template <int CODEC>
-__device__ __forceinline__ uint32_t warmup_entry(const uint8_t* data, uint64_t len, uint32_t lb, bool is_signed, int nbits) {
-  uint32_t sb = lb > RLE_WARMUP ? lb - RLE_WARMUP : 0u;
-  uint64_t p = (uint64_t)sb * RLE_BLK, target = (uint64_t)lb * RLE_BLK;
-  for (int hops = 0; p < target && p < len && hops < 8192; hops++) {
-    RunHdr h;
-    run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, h);
-    p += h.size;
-  }
-  uint64_t e = p - target;
-  return p < target ? 0u : (e > 0x7fffffffull ? 0x7fffffffu : (uint32_t)e);
 }
 
 // mode 0: guess; 1: relaxation round; 2: verify only; 3: strong blocks fill their pass-through blocks.
@@ -271,21 +259,6 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
         need = false;
       }
     }
-    uint32_t head_size = 0;
-    if (__ballot(need)) {
-      RunHdr hh;
-      if (j->codec == CODEC_RLE2) run_parse<CODEC_RLE2, false>(data, len ? len : 1, j->is_signed, j->nbits, hh);
-      else if (j->codec == CODEC_RLE1) run_parse<CODEC_RLE1, false>(data, len ? len : 1, j->is_signed, j->nbits, hh);
-      else run_parse<CODEC_BYTE, false>(data, len ? len : 1, false, 8, hh);
-      head_size = hh.size;
-    }
-    if (need && head_size < RLE_BLK / 2) {
-      // weak block of a short-run stream: entry from a warm-up walk that started a few KiB earlier
-      // (in long-run streams a block without a header is filled in by the strong block before it)
-      if (j->codec == CODEC_RLE2) want = warmup_entry<CODEC_RLE2>(data, len, lb, j->is_signed, j->nbits);
-      else if (j->codec == CODEC_RLE1) want = warmup_entry<CODEC_RLE1>(data, len, lb, j->is_signed, j->nbits);
-      else want = warmup_entry<CODEC_BYTE>(data, len, lb, false, 8);
-    }
     if (!in_job) return;
     if (!live) {
       blk.entry[b] = RLE_BLK;
@@ -357,6 +330,151 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
   blk.entry[b] = want;
   blk.exit_[b] = ex;
   blk.nvals[b] = nv;
+}
+
+// ---- short-run streams: exact intra-wave propagation out of LDS --------------------------------------
+// Blocks without a verified header ("weak") are typical of streams of short runs (SHORT_REPEAT,
+// small DIRECT groups, byte-RLE bitmaps).  One wavefront takes a span of 64 blocks plus a 32-block
+// warm-up in front of it into LDS (48 KiB) and iterates entry[l] = exit[l-1] across lanes until
+// nothing changes: inside the span the result is exactly what a serial walk would give, and the
+// warm-up makes the span's first entry right with overwhelming probability (a chain started at a
+// wrong byte merges with the true chain after a few run lengths).  Hops cost an LDS access instead
+// of a global-memory round trip.  Spans without weak blocks return at once.
+#define RLE_WARM 32u
+template <int CODEC>
+__device__ __forceinline__ void hop_lds(const uint8_t* buf, const uint8_t* data, uint64_t gstart, uint64_t gend, uint64_t len, uint64_t pos,
+                                        bool is_signed, int nbits, uint32_t& sz, uint32_t& n, uint32_t& err) {
+  // bytes a header parse may look at: 24 (RLE v2 window), 8 (byte RLE), a whole 128-varint literal group (RLE v1)
+  constexpr uint64_t LOOK = CODEC == CODEC_RLE1 ? 1320 : 24;
+  if (pos + LOOK <= gend) hop_parse<CODEC>(buf + (pos - gstart), len - pos, is_signed, nbits, sz, n, err);
+  else hop_parse<CODEC>(data + pos, len - pos, is_signed, nbits, sz, n, err);
+}
+
+// Walk block lbv from `entry` (headers come from LDS); value counts are recomputed by count_lds()
+// once the entries have converged.
+template <int CODEC>
+__device__ __forceinline__ void walk_lds(const uint8_t* buf, const uint8_t* data, uint64_t gstart, uint64_t gend, uint64_t len, uint32_t lbv,
+                                         uint32_t entry, bool is_signed, int nbits, unsigned long long*, unsigned long long*, uint32_t* exit_io) {
+  const uint64_t bend = (uint64_t)(lbv + 1) * RLE_BLK;
+  const uint64_t end = bend < len ? bend : len;
+  uint64_t pos = (uint64_t)lbv * RLE_BLK + entry;
+  while (pos < end) {
+    uint32_t sz, n, err;
+    hop_lds<CODEC>(buf, data, gstart, gend, len, pos, is_signed, nbits, sz, n, err);
+    pos += err ? 1u : sz;
+  }
+  *exit_io = pos > bend ? (uint32_t)(pos - bend) : 0u;
+}
+
+template <int CODEC>
+__device__ __forceinline__ uint32_t count_lds(const uint8_t* buf, const uint8_t* data, uint64_t gstart, uint64_t gend, uint64_t len, uint32_t lbv,
+                                              uint32_t entry, bool is_signed, int nbits) {
+  const uint64_t bend = (uint64_t)(lbv + 1) * RLE_BLK;
+  const uint64_t end = bend < len ? bend : len;
+  uint64_t pos = (uint64_t)lbv * RLE_BLK + entry;
+  uint32_t nv = 0;
+  while (pos < end) {
+    uint32_t sz, n, err;
+    hop_lds<CODEC>(buf, data, gstart, gend, len, pos, is_signed, nbits, sz, n, err);
+    nv += n;
+    pos += err ? 1u : sz;
+  }
+  return nv;
+}
+
+template <int CODEC>
+__device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t lb0, uint32_t b0g, uint8_t* buf,
+                                           unsigned long long* seen_all, unsigned long long* fresh_all, uint32_t lane, bool live, bool weak) {
+  const uint8_t* data = j->data;
+  const bool is_signed = j->is_signed;
+  const int nbits = j->nbits;
+  const uint32_t wstart = lb0 >= RLE_WARM ? lb0 - RLE_WARM : 0u;
+  const uint32_t nwarm = lb0 - wstart;
+  const uint64_t gstart = (uint64_t)wstart * RLE_BLK;
+  uint64_t gend = (uint64_t)(lb0 + 64) * RLE_BLK + ORC_PAD;
+  if (gend > len + ORC_PAD) gend = len + ORC_PAD;
+  unsigned long long* seen = seen_all + lane;
+  unsigned long long* fresh = fresh_all + lane;
+  // stage the bytes (coalesced 16-byte pieces)
+  for (uint64_t o0 = (uint64_t)lane * 16; gstart + o0 < gend; o0 += 8 * 64 * 16) {
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      uint64_t o = o0 + (uint64_t)u * 64 * 16;
+      if (gstart + o < gend) __builtin_memcpy(&v[u], data + gstart + o, 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      uint64_t o = o0 + (uint64_t)u * 64 * 16;
+      if (gstart + o < gend) __builtin_memcpy(buf + o, &v[u], 16);
+    }
+  }
+  for (int k = 0; k < 8; k++) seen[k * 64] = 0;
+  wave_sync_scan();
+  uint32_t E = 0;
+  const bool first_weak = __shfl((int)weak, 0);
+  if (nwarm > 0 && first_weak) {
+    // warm-up phase: lanes 0..nwarm-1 own the blocks in front of the span
+    uint32_t e = 0, ex = 0;
+    bool dirty = lane < nwarm;
+    for (int it = 0; it < 64; it++) {
+      if (dirty) walk_lds<CODEC>(buf, data, gstart, gend, len, wstart + lane, e, is_signed, nbits, seen, fresh, &ex);
+      uint32_t prev = __shfl_up(ex, 1);
+      uint32_t ne = (lane == 0 || lane >= nwarm) ? e : prev;
+      dirty = ne != e;
+      e = ne;
+      if (!__ballot(dirty)) break;
+    }
+    E = __shfl(ex, nwarm - 1);
+    for (int k = 0; k < 8; k++) seen[k * 64] = 0;
+  }
+  // span phase
+  uint32_t b = b0g + lane;
+  uint32_t e = 0, ex = 0;
+  if (live) e = weak ? (lane == 0 ? (lb0 == 0 ? 0u : E) : 0u) : blk.entry[b];
+  bool dirty = live;
+  for (int it = 0; it < 96; it++) {
+    if (dirty) {
+      if (e >= RLE_BLK) {
+        ex = e - RLE_BLK;
+        for (int k = 0; k < 8; k++) seen[k * 64] = 0;
+      } else {
+        walk_lds<CODEC>(buf, data, gstart, gend, len, lb0 + lane, e, is_signed, nbits, seen, fresh, &ex);
+      }
+    }
+    uint32_t prev = __shfl_up(ex, 1);
+    uint32_t ne = (weak && lane > 0) ? prev : e;
+    dirty = live && ne != e;
+    e = ne;
+    if (!__ballot(dirty)) break;
+  }
+  if (live && weak) {
+    uint32_t nv = e >= RLE_BLK ? 0u : count_lds<CODEC>(buf, data, gstart, gend, len, lb0 + lane, e, is_signed, nbits);
+    blk.entry[b] = e;
+    blk.exit_[b] = ex;
+    blk.nvals[b] = nv;
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(64) rle_walk_short_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
+                                                                        uint32_t total_blocks) {
+  __shared__ __attribute__((aligned(16))) uint8_t buf[(64 + RLE_WARM) * RLE_BLK + 2 * ORC_PAD];
+  __shared__ unsigned long long seen[8 * 64];
+  __shared__ unsigned long long fresh[8 * 64];
+  uint32_t lane = threadIdx.x;
+  uint32_t bw = blockIdx.x * 64u;
+  if (bw >= total_blocks) return;
+  RleJob* j = const_cast<RleJob*>(find_job_by_block(jobs, njobs, bw));
+  uint32_t lb0 = bw - j->block0;
+  uint32_t lb = lb0 + lane;
+  uint64_t len = scalars[j->len_idx];
+  bool live = lb < j->nblocks && ((uint64_t)lb * RLE_BLK < len || lb == 0);
+  bool weak = live && !blk.flags[bw + lane];
+  // isolated weak blocks inside long-run streams are left to the relaxation rounds
+  if (__builtin_popcountll(__ballot(weak)) < 16) return;
+  if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live, weak);
+  else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live, weak);
+  else short_span<CODEC_BYTE>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live, weak);
 }
 
 // Repair of whatever the relaxation rounds left inconsistent (long runs of irregular size never
