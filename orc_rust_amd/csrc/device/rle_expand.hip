@@ -125,6 +125,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
 
   uint32_t lb = lg * G + lane;
   bool active = false, tail_owner = false;
+  bool clean = true;  // no failing run seen by this lane
   uint64_t pos = 0, end = 0;
   uint64_t oi = 0;
   if (lane < G && lb < j->nblocks && ((uint64_t)lb * RLE_BLK < len || lb == 0)) {
@@ -137,7 +138,6 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
     active = e < RLE_BLK && pos < end && oi < needed;
     tail_owner = (lb == 0 && len == 0) || (e < RLE_BLK && pos < end);
   }
-  bool clean = true;  // no failing run seen by this lane
 
   // Lane l < G owns block l of the group and walks its run chain; per iteration it hands out up to
   // K = 64 / G consecutive runs into "slots" l*K .. l*K+K-1, then every lane parses ONE slot in full.
@@ -251,6 +251,21 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
               va[u] = is_signed ? zigzag_n(a, 64) : (int64_t)a;
               vb[u] = is_signed ? zigzag_n(b, 64) : (int64_t)b;
             }
+          } else if (type == RT_DELTA) {
+            // fixed delta: an arithmetic progression.  The reference checks every step; the sequence
+            // is monotonic, so the last value of this 512-value segment decides (exact, in 128 bit).
+            const int64_t step = dlt;  // sign of delta_base picks add / subtract (delta.rs:77-82): +d or -|d| = d either way
+            const uint64_t first = (uint64_t)base + (uint64_t)(i0 + 2 * lane) * (uint64_t)step;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              va[u] = (int64_t)(first + (uint64_t)(u * 128) * (uint64_t)step);
+              vb[u] = (int64_t)((uint64_t)va[u] + (uint64_t)step);
+            }
+            __int128 last = (__int128)base + (__int128)(i0 + 511) * (__int128)step;
+            bad = last > (__int128)INT64_MAX || last < (__int128)INT64_MIN;
+          } else if (type == RT_SR || type == RT_B_RUN) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) va[u] = vb[u] = base;
           } else {
 #pragma unroll
             for (int u = 0; u < 4; u++) {

@@ -166,6 +166,40 @@ def test_error_cases():
                 G.assert_column_parity(res, 0, cols[0], streams, n, batch, what=(name, typ, batch))
 
 
+def _zz_varint(v):
+    u = (v << 1) ^ (v >> 63) if v >= 0 else ((-v) << 1) - 1
+    out = bytearray()
+    while True:
+        b = u & 0x7F
+        u >>= 7
+        if u:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+@pytest.mark.parametrize("where", [None, 3, 150, 199])
+@pytest.mark.parametrize("step", [3, -3, 0])
+def test_fixed_delta_full_runs(where, step):
+    """200 fixed-delta runs of 512 values (closed-form path of the expansion); optionally one run whose
+    progression leaves the i64 range part-way (the reference fails on the first overflowing add)."""
+    runs, n = 200, 200 * 512
+    data = bytearray()
+    for r in range(runs):
+        base = r * 10_000 - 1_000_000
+        if where is not None and r == where and step != 0:
+            base = ((1 << 63) - 1 - 700) if step > 0 else (-(1 << 63) + 700)
+        data += bytes([0xC1, 0xFF]) + _zz_varint(base) + _zz_varint(step)
+    data = np.frombuffer(bytes(data), dtype=np.uint8)
+    cols = [col(1, LONG)]
+    streams = [(1, DATA, data)]
+    for batch in (8192, 1000):
+        res = G.gpu_decode(n, cols, streams, batch_size=batch)
+        G.assert_column_parity(res, 0, cols[0], streams, n, batch, what=("fixed-delta", where, step, batch))
+        res.free()
+
+
 def test_strings_direct_and_dictionary():
     STRING, BINARY, LENGTH, DICT = 7, 8, 2, 3
     n = 30000
