@@ -110,9 +110,18 @@ __device__ __forceinline__ int64_t decode_b1(uint32_t type, uint32_t w, int64_t 
   return v;
 }
 
+// 16 payload bytes for each of a lane's four value pairs (values i0 + 128u + 2*lane, +1) of a DIRECT run
+__device__ __forceinline__ void direct_pair_load(const uint8_t* pp, uint32_t i0, uint32_t w, uint32_t lane, uint64_t (*pf)[2]) {
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    uint64_t bit = (uint64_t)(i0 + u * 128 + 2 * lane) * w;
+    __builtin_memcpy(pf[u], pp + (bit >> 3), 16);
+  }
+}
+
 template <int CODEC, int OB>
 __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, const uint64_t* scalars, uint32_t lg, WaveLds& L,
-                                             uint32_t lane) {
+                                             uint32_t lane PROF_PARM) {
   const uint8_t* data = j->data;
   void* out = j->out;
   const uint64_t len = scalars[j->len_idx];
@@ -123,6 +132,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
   const uint32_t G = j->group_size;
   const uint32_t eof_code = CODEC == CODEC_BYTE ? ORC_E_IO : ORC_E_OUT_OF_SPEC;
 
+  PROF_MARK(8);
   uint32_t lb = lg * G + lane;
   bool active = false, tail_owner = false;
   bool clean = true;  // no failing run seen by this lane
@@ -144,10 +154,15 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
   // G = 64: one run per block per iteration; G = 1 (streams that expand a lot, e.g. fixed DELTA):
   // 64 consecutive runs of the single block are expanded together.
   const uint32_t K = 64u / G;
+  PROF_MARK(10);
   for (;;) {
     L.spos[lane] = ~0ull;
     wave_sync();
-    if (active) {
+    if (active && K == 1) {
+      // one run per block and trip: the owner parses its own slot in full below (one header fetch, not two)
+      L.spos[lane] = pos;
+      L.soi[lane] = (uint32_t)oi;
+    } else if (active) {
       uint64_t p = pos, o = oi;
       for (uint32_t k = 0; k < K && p < end && o < needed; k++) {
         RunHdr hh;
@@ -163,6 +178,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
       active = clean && pos < end && oi < needed;
     }
     wave_sync();
+    PROF_MARK(11);
     const uint64_t sp = L.spos[lane];
     const bool has = sp != ~0ull;
     if (!__ballot(has)) break;
@@ -176,6 +192,12 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
     if (has) {
       const uint64_t soi = L.soi[lane];
       run_parse<CODEC, true>(data + sp, len - sp, is_signed, nbits, h);
+      if (K == 1) {
+        if (h.err) clean = false;
+        pos = sp + h.size;
+        oi = soi + h.n;
+        active = clean && pos < end && oi < needed;
+      }
       if (h.err) {
         report(j, needed, soi, h.err);
       } else {
@@ -197,6 +219,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
     uint32_t T = __shfl(incl, 63);
     if (lane == 63) L.start[64] = T;
     wave_sync();
+    PROF_MARK(12);
 
     // ---- B1: value-parallel expansion of the random-access runs -----------------------------
     {
@@ -237,13 +260,13 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           bool bad = false;
           int64_t va[4], vb[4];
           if (type == RT_DIRECT) {
+            uint64_t pf[4][2];
+            direct_pair_load(pp, i0, w, lane, pf);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
               uint32_t idx = i0 + u * 128 + 2 * lane;
               uint64_t bit = (uint64_t)idx * w;
-              uint64_t raw[2];
-              __builtin_memcpy(raw, pp + (bit >> 3), 16);
-              uint64_t hi = __builtin_bswap64(raw[0]), lo = __builtin_bswap64(raw[1]);
+              uint64_t hi = __builtin_bswap64(pf[u][0]), lo = __builtin_bswap64(pf[u][1]);
               uint32_t sh = bit & 7, t = sh + w;
               uint64_t a = (hi << sh) >> (64 - w);
               uint64_t top = t < 64 ? ((hi << t) | (lo >> (64 - t))) : (lo << (t - 64));
@@ -329,8 +352,19 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
       }
     }
 
+    PROF_MARK(13);
     // ---- B2: runs with an internal dependency, one run at a time, whole wave ------------------
     unsigned long long m2 = __ballot(has && is_b2 && !h.err);
+    // varying-DELTA runs with deltas of <= 8 bits: a lane's 8 deltas are `w` contiguous bytes; the
+    // load for the NEXT run is issued before the current run is scanned and stored
+    uint64_t raw_next = 0;
+    auto delta_prefetch = [&](uint32_t rr) -> uint64_t {
+      const uint32_t mt = L.meta[rr];
+      const uint32_t ww = (mt >> 8) & 0xff, nn = mt >> 16;
+      if (CODEC != CODEC_RLE2 || (mt & 0xff) != RT_DELTA || ww > 8 || lane * 8 >= nn - 2) return 0;
+      return ld_u64(data + L.pay[rr] + lane * ww);
+    };
+    if (CODEC == CODEC_RLE2 && m2) raw_next = delta_prefetch((uint32_t)__builtin_ctzll(m2));
     while (m2) {
       uint32_t r = (uint32_t)__builtin_ctzll(m2);
       m2 &= m2 - 1;
@@ -340,6 +374,8 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
       uint64_t o0 = L.oidx[r];
       const uint8_t* pp = data + L.pay[r];
       bool bad = false;
+      const uint64_t raw_cur = raw_next;
+      if (CODEC == CODEC_RLE2 && m2) raw_next = delta_prefetch((uint32_t)__builtin_ctzll(m2));
       if (CODEC == CODEC_RLE2 && type == RT_DELTA) {
         // varying delta (delta.rs:94-113)
         int64_t db = L.delta[r];
@@ -353,24 +389,24 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
         // 8-byte load), sums them locally, ONE wave scan over the lane totals gives every prefix,
         // and an LDS transpose turns the lane-major results into coalesced stores.
         const uint32_t nd = n - 2;
-        int64_t dl[8];
+        // only the running sums are kept (a delta is the difference of two neighbours): registers
+        uint64_t pre[8];
         uint64_t run = 0;
-        if (w == 8) {
-          uint64_t raw = ld_u64(pp + lane * 8);  // 8 one-byte deltas in one load
+        if (w <= 8) {
+          const uint64_t be = __builtin_bswap64(raw_cur);  // MSB-first bit stream (integer/util.rs:44-218)
 #pragma unroll
-          for (int k = 0; k < 8; k++) dl[k] = lane * 8 + k < nd ? (int64_t)((raw >> (8 * k)) & 0xff) : 0;
+          for (int k = 0; k < 8; k++) {
+            uint64_t dk = w == 8 ? ((raw_cur >> (8 * k)) & 0xff) : ((be << (k * w)) >> (64 - w));
+            run += lane * 8 + k < nd ? dk : 0;
+            pre[k] = run;
+          }
         } else {
 #pragma unroll
           for (int k = 0; k < 8; k++) {
             uint32_t i = lane * 8 + k;
-            dl[k] = i < nd ? (int64_t)unpack_be(pp, i, w) : 0;
+            run += i < nd ? unpack_be(pp, i, w) : 0;
+            pre[k] = run;
           }
-        }
-        uint64_t pre[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          run += (uint64_t)dl[k];
-          pre[k] = run;
         }
         uint64_t incl = wave_incl_scan_u64(run, lane);
         uint64_t excl = incl - run;
@@ -378,9 +414,10 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
         for (int k = 0; k < 8; k++) {
           uint32_t i = lane * 8 + k;
           uint64_t sfx = excl + pre[k];
+          int64_t dk = (int64_t)(pre[k] - (k ? pre[k - 1] : 0));
           int64_t v = add ? (int64_t)((uint64_t)v1 + sfx) : (int64_t)((uint64_t)v1 - sfx);
-          int64_t prev = add ? (int64_t)((uint64_t)v - (uint64_t)dl[k]) : (int64_t)((uint64_t)v + (uint64_t)dl[k]);
-          if (i < nd) bad |= (add ? add_ovf(prev, dl[k], v) : sub_ovf(prev, dl[k], v)) || !in_range_n(v, nbits);
+          int64_t prev = add ? (int64_t)((uint64_t)v - (uint64_t)dk) : (int64_t)((uint64_t)v + (uint64_t)dk);
+          if (i < nd) bad |= (add ? add_ovf(prev, dk, v) : sub_ovf(prev, dk, v)) || !in_range_n(v, nbits);
           L.tile[i + (i >> 3)] = v;
         }
         wave_sync();
@@ -476,47 +513,45 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
       }
     }
     wave_sync();
+    PROF_MARK(14);
   }
   // clean end of stream before `needed` values: "not enough values to decode"
   if (tail_owner && clean && pos >= len) report(j, needed, oi, eof_code);
 }
 
 template <int CODEC>
-__device__ __forceinline__ void expand_entry(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars, uint32_t total_groups) {
+__device__ __forceinline__ void expand_entry(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars, uint32_t total_groups) {
   __shared__ WaveLds lds[4];
   uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t g = blockIdx.x * 4 + wv;
   if (g >= total_groups) return;
-  int lo = 0, hi = njobs - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].group0 <= g) lo = mid;
-    else hi = mid - 1;
-  }
-  RleJob* j = &jobs[lo];
+  PROF_BEGIN();
+  RleJob* j = &jobs[group_job[g]];
   uint32_t lg = g - j->group0;
   if (lg >= j->ngroups) return;
+  PROF_MARK(9);
   if (CODEC == CODEC_BYTE) {
-    expand_group<CODEC, 1>(j, blk, scalars, lg, lds[wv], lane);
+    expand_group<CODEC, 1>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
   } else {
     // wave-uniform dispatch on the value width: the bodies are specialised at compile time
     switch (j->out_bytes) {
-      case 8: expand_group<CODEC, 8>(j, blk, scalars, lg, lds[wv], lane); break;
-      case 4: expand_group<CODEC, 4>(j, blk, scalars, lg, lds[wv], lane); break;
-      default: expand_group<CODEC, 2>(j, blk, scalars, lg, lds[wv], lane); break;
+      case 8: expand_group<CODEC, 8>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;
+      case 4: expand_group<CODEC, 4>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;
+      default: expand_group<CODEC, 2>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;
     }
   }
+  PROF_END();
 }
 
-extern "C" __global__ void __launch_bounds__(256, ORC_EXPAND_WAVES) rle2_expand_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
+extern "C" __global__ void __launch_bounds__(256, ORC_EXPAND_WAVES) rle2_expand_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,
                                                                       uint32_t total_groups) {
-  expand_entry<CODEC_RLE2>(jobs, njobs, blk, scalars, total_groups);
+  expand_entry<CODEC_RLE2>(jobs, group_job, blk, scalars, total_groups);
 }
-extern "C" __global__ void __launch_bounds__(256) rle1_expand_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
+extern "C" __global__ void __launch_bounds__(256) rle1_expand_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,
                                                                       uint32_t total_groups) {
-  expand_entry<CODEC_RLE1>(jobs, njobs, blk, scalars, total_groups);
+  expand_entry<CODEC_RLE1>(jobs, group_job, blk, scalars, total_groups);
 }
-extern "C" __global__ void __launch_bounds__(256) byte_expand_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
+extern "C" __global__ void __launch_bounds__(256) byte_expand_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,
                                                                       uint32_t total_groups) {
-  expand_entry<CODEC_BYTE>(jobs, njobs, blk, scalars, total_groups);
+  expand_entry<CODEC_BYTE>(jobs, group_job, blk, scalars, total_groups);
 }

@@ -19,6 +19,8 @@ struct RleJob {
   uint32_t group0;         // first global expansion group
   uint32_t ngroups;
   uint32_t group_size;     // blocks per wavefront in the expansion (1..64)
+  uint32_t group_tab0;     // index of this job's first group in RleBlocks::group_job
+  uint32_t class_index;    // index of the job inside its class (what group_job holds)
   uint8_t codec;           // CODEC_*
   uint8_t is_signed;
   uint8_t nbits;           // width of the reference's NInt (8 for byte RLE)
@@ -37,4 +39,5 @@ struct RleBlocks {
   uint32_t* tile_base;  // per tile: values before the tile (within the job)
   uint8_t* flags;       // 1 = strong: entry verified by the candidate search (or filled by a strong owner)
   uint32_t* badmap;     // 1 bit per block: inconsistent at the verify round (zeroed every call)
+  uint32_t* group_job;  // per expansion group: class-relative job index (one table per job class, back to back)
 };

@@ -25,6 +25,43 @@
 #include "rle_kernels.h"
 #include "rle_parse.h"
 
+// Phase timing for development builds (-DORC_PROF): per-phase sum / max of wavefront wall-clock ticks (10 ns).
+#ifdef ORC_PROF
+__device__ unsigned long long g_prof[48];
+struct Prof {
+  unsigned long long t;
+  unsigned long long acc[16];
+};
+#define PROF_BEGIN()            \
+  Prof prof;                    \
+  for (int i_ = 0; i_ < 16; i_++) prof.acc[i_] = 0; \
+  prof.t = wall_clock64()
+#define PROF_MARK(i)                         \
+  do {                                       \
+    unsigned long long t_ = wall_clock64();  \
+    prof.acc[(i) & 15] += t_ - prof.t;       \
+    prof.t = t_;                             \
+  } while (0)
+#define PROF_END()                                              \
+  do {                                                          \
+    if ((threadIdx.x & 63) == 0) {                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++)         \
+        if (prof.acc[i_]) {                                     \
+          atomicAdd(&g_prof[2 * i_], prof.acc[i_]);             \
+          atomicMax(&g_prof[2 * i_ + 1], prof.acc[i_]);         \
+        }                                                       \
+    }                                                           \
+  } while (0)
+#define PROF_ARG , prof
+#define PROF_PARM , Prof& prof
+#else
+#define PROF_ARG
+#define PROF_PARM
+#define PROF_MARK(i)
+#define PROF_BEGIN()
+#define PROF_END()
+#endif
+
 __device__ __forceinline__ void wave_sync_scan() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -71,25 +108,39 @@ __device__ __forceinline__ void walk_dispatch(const RleJob* j, const uint8_t* da
 }
 
 // A "full run" header at p that is followed by `hops` more headers of the same kind.
+// `bm` (optional): prefilter bitmaps of the 64 blocks from byte `wbase` on -- a header position whose
+// bit is clear cannot start a full run (rejects without touching memory), and a set bit stands in
+// for the last hop's parse.
 template <int CODEC>
-__device__ __forceinline__ bool plausible_header(const uint8_t* data, uint64_t len, uint64_t p, bool is_signed, int nbits, uint32_t* size_out = nullptr) {
-  RunHdr h;
-  run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, h);
-  if (h.err) return false;
-  if (size_out) *size_out = h.size;
+__device__ __forceinline__ bool plausible_header(const uint8_t* data, uint64_t len, uint64_t p, bool is_signed, int nbits, uint32_t* size_out = nullptr,
+                                                 const unsigned long long (*bm)[8] = nullptr, uint64_t wbase = 0) {
+  // lean parse (size / count only); the run type comes from the header byte itself
+  uint32_t hsize, hn, herr;
+  hop_parse<CODEC>(data + p, len - p, is_signed, nbits, hsize, hn, herr);
+  if (herr) return false;
+  if (size_out) *size_out = hsize;
+  const uint32_t hb = data[p];
   if (CODEC == CODEC_RLE2) {
-    if (h.n != 512 || h.type == RT_SR) return false;
+    if (hn != 512 || (hb >> 6) == RT_SR) return false;
   } else {
-    if (h.n != 128 || (h.type != RT_B_LIT && h.type != RT_V1_LIT)) return false;
+    if (hn != 128 || hb < 0x80) return false;  // 128 literals
   }
-  uint64_t q = p + h.size;
+  uint64_t q = p + hsize;
   const int hops = CODEC == CODEC_RLE2 ? 2 : 3;
   for (int i = 0; i < hops; i++) {
     if (q == len) return true;
-    RunHdr g;
-    run_parse<CODEC, false>(data + q, len - q, is_signed, nbits, g);
-    if (g.err || g.n != h.n || g.type != h.type) return false;
-    q += g.size;
+    if (q > len) return false;
+    if (bm && q >= wbase && q - wbase < 64ull * RLE_BLK) {
+      uint64_t o = q - wbase;
+      bool set = (bm[o >> 9][(o >> 6) & 7] >> (o & 63)) & 1;
+      if (!set) return false;
+      if (i == hops - 1) return true;
+    }
+    uint32_t gsize, gn, gerr;
+    hop_parse<CODEC>(data + q, len - q, is_signed, nbits, gsize, gn, gerr);
+    const uint32_t gb = data[q];
+    if (gerr || gn != hn || (CODEC == CODEC_RLE2 ? (gb >> 6) != (hb >> 6) : gb < 0x80)) return false;
+    q += gsize;
   }
   return true;
 }
@@ -117,9 +168,50 @@ __device__ __forceinline__ uint32_t prefilter8(uint64_t w, uint64_t nx) {
 // verifies the candidates in order.  Returns the verified entry (or RLE_BLK).
 template <int CODEC>
 __device__ __forceinline__ uint32_t wave_find_candidates(const uint8_t* data, uint64_t len, uint32_t lb, bool need, bool is_signed, int nbits,
-                                                         unsigned long long (*bm)[8], uint32_t lane) {
+                                                         unsigned long long (*bm)[8], uint32_t lane PROF_PARM) {
   unsigned long long todo = __ballot(need);
   uint32_t lb0 = lb - lane;  // first block of the wave (wave-uniform)
+  const uint64_t wbase = (uint64_t)lb0 * RLE_BLK;
+  // dense: most blocks of the window need a search -> read the whole 32 KiB window with 16-byte loads
+  // (1 KiB = two blocks per instruction, eight instructions in flight)
+  const bool dense = __popcll(todo) >= 24;
+  if (dense) {
+    // neighbouring wavefronts start in different quarters of their windows: in lockstep they would
+    // all hit the same memory channels at the same time
+    const int rot = (int)((lb0 >> 6) & 3) * 8;
+    for (int it = 0; it < 32; it += 8) {
+      const int i0 = (it + rot) & 31;
+      uint64_t lo[8], hi[8];
+      uint32_t edge[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        uint64_t p = wbase + (uint64_t)(i0 + u) * 1024 + lane * 16;
+        bool in = p < len;  // the staged stream carries ORC_PAD readable bytes past len
+        lo[u] = 0, hi[u] = 0;
+        if (in) {
+          uint64_t v[2];
+          __builtin_memcpy(v, data + p, 16);
+          lo[u] = v[0], hi[u] = v[1];
+        }
+        edge[u] = (lane == 63 && p + 16 < len) ? data[p + 16] : 0u;  // the byte after the instruction's 1 KiB
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        uint64_t p = wbase + (uint64_t)(i0 + u) * 1024 + lane * 16;
+        uint32_t nxt = __shfl_down((uint32_t)(lo[u] & 0xff), 1);
+        if (lane == 63) nxt = edge[u];
+        uint64_t nlo = (lo[u] >> 8) | (hi[u] << 56), nhi = (hi[u] >> 8) | ((uint64_t)nxt << 56);
+        uint32_t bits = 0;
+        if (p < len) {
+          bits = prefilter8<CODEC>(lo[u], nlo) | (prefilter8<CODEC>(hi[u], nhi) << 8);
+          uint64_t rem = len - p;
+          if (rem < 16) bits &= (1u << rem) - 1;
+        }
+        reinterpret_cast<uint16_t*>(bm[2 * (i0 + u) + (lane >> 5)])[lane & 31] = (uint16_t)bits;
+      }
+    }
+    todo = 0;
+  }
   while (todo) {
     // four blocks per trip: all loads are issued before any of them is consumed
     uint32_t kk[4];
@@ -147,10 +239,17 @@ __device__ __forceinline__ uint32_t wave_find_candidates(const uint8_t* data, ui
     }
   }
   wave_sync_scan();
+  PROF_MARK(1);
   uint32_t found = RLE_BLK;
+#ifdef ORC_PROF
+  int g_tries = 0;
+#endif
   if (need) {
     const uint64_t b0 = (uint64_t)lb * RLE_BLK;
     int tries = 0;
+#ifdef ORC_PROF
+    g_tries = 0;
+#endif
     for (int wi = 0; wi < 8 && found == RLE_BLK && tries < 6; wi++) {
       unsigned long long m = bm[lane][wi];
       while (m && tries < 6) {
@@ -158,7 +257,10 @@ __device__ __forceinline__ uint32_t wave_find_candidates(const uint8_t* data, ui
         m &= m - 1;
         uint64_t c = b0 + wi * 64 + i;
         tries++;
-        if (plausible_header<CODEC>(data, len, c, is_signed, nbits)) {
+#ifdef ORC_PROF
+        g_tries++;
+#endif
+        if (plausible_header<CODEC>(data, len, c, is_signed, nbits, nullptr, dense ? bm : nullptr, wbase)) {
           found = (uint32_t)(c - b0);
           break;
         }
@@ -166,6 +268,23 @@ __device__ __forceinline__ uint32_t wave_find_candidates(const uint8_t* data, ui
     }
   }
   wave_sync_scan();
+  PROF_MARK(2);
+#ifdef ORC_PROF
+  {
+    uint32_t t = need ? (uint32_t)g_tries : 0u, s = t;
+    for (int off = 32; off; off >>= 1) {
+      uint32_t o = __shfl_xor(t, off);
+      t = o > t ? o : t;
+      s += __shfl_xor(s, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&g_prof[32], t);
+      atomicMax(&g_prof[33], t);
+      atomicAdd(&g_prof[34], s);
+      atomicAdd(&g_prof[36], 1);
+    }
+  }
+#endif
   return found;
 }
 
@@ -190,6 +309,7 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
   uint32_t lane = threadIdx.x & 63;
   uint32_t bw = b - lane;  // first block of this wavefront
   if (bw >= total_blocks) return;
+  PROF_BEGIN();
   RleJob* j = const_cast<RleJob*>(find_job_by_block(jobs, njobs, bw));
   uint32_t lb = b - j->block0;
   uint64_t len = scalars[j->len_idx];
@@ -197,6 +317,7 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
   bool live = in_job && ((uint64_t)lb * RLE_BLK < len || lb == 0);
   const uint8_t* data = j->data;
   if (mode == 0) {
+    if ((b & 31) == 0) blk.badmap[b >> 5] = 0;  // the verify round marks blocks here
     uint32_t want = 0, strong = 0;
     bool need = false;
     if (live) {
@@ -247,19 +368,24 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
         }
       }
     }
+    if (mode == 0) PROF_MARK(0);
     if (__ballot(need)) {
       uint32_t cand;
       unsigned long long(*bm)[8] = bitmaps[threadIdx.x >> 6];
-      if (j->codec == CODEC_RLE2) cand = wave_find_candidates<CODEC_RLE2>(data, len, lb, need, j->is_signed, j->nbits, bm, lane);
-      else if (j->codec == CODEC_RLE1) cand = wave_find_candidates<CODEC_RLE1>(data, len, lb, need, j->is_signed, j->nbits, bm, lane);
-      else cand = wave_find_candidates<CODEC_BYTE>(data, len, lb, need, false, 8, bm, lane);
+      if (j->codec == CODEC_RLE2) cand = wave_find_candidates<CODEC_RLE2>(data, len, lb, need, j->is_signed, j->nbits, bm, lane PROF_ARG);
+      else if (j->codec == CODEC_RLE1) cand = wave_find_candidates<CODEC_RLE1>(data, len, lb, need, j->is_signed, j->nbits, bm, lane PROF_ARG);
+      else cand = wave_find_candidates<CODEC_BYTE>(data, len, lb, need, false, 8, bm, lane PROF_ARG);
       if (need && cand < RLE_BLK) {
         want = cand;
         strong = 1;
         need = false;
       }
     }
-    if (!in_job) return;
+    PROF_MARK(3);
+    if (!in_job) {
+      blk.nvals[b] = 0;  // tile padding behind the job's last block: the scans read it
+      return;
+    }
     if (!live) {
       blk.entry[b] = RLE_BLK;
       blk.exit_[b] = 0;
@@ -278,6 +404,64 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
     blk.exit_[b] = ex;
     blk.nvals[b] = nv;
     blk.flags[b] = (uint8_t)strong;
+    PROF_MARK(4);
+    PROF_END();
+    return;
+  }
+  if (mode == 1) {
+    // Relaxation: entry[b] must equal exit[b-1].  Up to four sweeps per launch run inside the
+    // wavefront (the predecessor's exit comes from the neighbouring lane; lane 0 reads the previous
+    // wavefront's last block from memory, so chains across wavefronts need another launch).
+    uint32_t e = RLE_BLK, ex = 0, nv = 0, fl = 0;
+    if (live) {
+      e = blk.entry[b];
+      ex = blk.exit_[b];
+      fl = blk.flags[b];
+    }
+    uint32_t pex0 = 0, pfl0 = 0;
+    if (live && lb > 0 && lane == 0) {
+      pex0 = blk.exit_[b - 1];
+      pfl0 = blk.flags[b - 1];
+    }
+    bool dirty = false;
+    for (int sweep = 0; sweep < 4; sweep++) {
+      uint32_t pex = __shfl_up(ex, 1), pfl = __shfl_up(fl, 1);
+      if (lane == 0) pex = pex0, pfl = pfl0;
+      bool change = false;
+      if (live && lb > 0 && pex != e) {
+        // A strong block ignores a weak predecessor (its exit may be garbage).  A STRONG predecessor's
+        // exit always lies on the true chain -- a false candidate only passes verification by hopping
+        // onto it -- so when the two disagree this block keeps its entry only if its own chain
+        // reaches the predecessor's header exactly (then the predecessor skipped runs, not us).
+        bool keep = false;
+        if (fl) {
+          if (!pfl) {
+            keep = true;
+          } else if (e < pex && e < RLE_BLK) {
+            uint64_t from = (uint64_t)lb * RLE_BLK + e, target = (uint64_t)lb * RLE_BLK + pex;
+            if (j->codec == CODEC_RLE2) keep = chain_hits<CODEC_RLE2>(data, len, from, target, j->is_signed, j->nbits);
+            else if (j->codec == CODEC_RLE1) keep = chain_hits<CODEC_RLE1>(data, len, from, target, j->is_signed, j->nbits);
+            else keep = chain_hits<CODEC_BYTE>(data, len, from, target, false, 8);
+          }
+        }
+        if (!keep) {
+          if (pex >= RLE_BLK) {
+            ex = pex - RLE_BLK;
+            nv = 0;
+          } else {
+            walk_dispatch(j, data, len, lb, pex, &ex, &nv);
+          }
+          e = pex;
+          change = dirty = true;
+        }
+      }
+      if (!__ballot(change)) break;
+    }
+    if (dirty) {
+      blk.entry[b] = e;
+      blk.exit_[b] = ex;
+      blk.nvals[b] = nv;
+    }
     return;
   }
   if (!live) return;
@@ -295,41 +479,12 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
     }
     return;
   }
-  if (mode == 1 && lb == 0) return;
+  // mode 2: verify
   uint32_t want = lb == 0 ? 0u : blk.exit_[b - 1];
   if (want == blk.entry[b]) return;
-  if (mode == 1 && blk.flags[b]) {
-    // A strong block ignores a weak predecessor (its exit may be garbage).  A STRONG predecessor's
-    // exit always lies on the true chain -- a false candidate only passes verification by hopping
-    // onto it -- so when the two disagree this block keeps its entry only if its own chain
-    // reaches the predecessor's header exactly (then the predecessor skipped runs, not us).
-    if (!blk.flags[b - 1]) return;
-    uint32_t e = blk.entry[b];
-    if (e < want && e < RLE_BLK) {
-      uint64_t from = (uint64_t)lb * RLE_BLK + e, target = (uint64_t)lb * RLE_BLK + want;
-      bool hits;
-      if (j->codec == CODEC_RLE2) hits = chain_hits<CODEC_RLE2>(data, len, from, target, j->is_signed, j->nbits);
-      else if (j->codec == CODEC_RLE1) hits = chain_hits<CODEC_RLE1>(data, len, from, target, j->is_signed, j->nbits);
-      else hits = chain_hits<CODEC_BYTE>(data, len, from, target, false, 8);
-      if (hits) return;
-    }
-  }
-  if (mode == 2) {
-    atomicMin(&j->first_bad, lb);
-    atomicAdd(&j->stat_bad, 1u);
-    atomicOr(&blk.badmap[b >> 5], 1u << (b & 31));
-    return;
-  }
-  uint32_t ex, nv;
-  if (want >= RLE_BLK) {
-    ex = want - RLE_BLK;
-    nv = 0;
-  } else {
-    walk_dispatch(j, data, len, lb, want, &ex, &nv);
-  }
-  blk.entry[b] = want;
-  blk.exit_[b] = ex;
-  blk.nvals[b] = nv;
+  atomicMin(&j->first_bad, lb);
+  atomicAdd(&j->stat_bad, 1u);
+  atomicOr(&blk.badmap[b >> 5], 1u << (b & 31));
 }
 
 // ---- short-run streams: exact intra-wave propagation out of LDS --------------------------------------
@@ -462,19 +617,29 @@ extern "C" __global__ void __launch_bounds__(64) rle_walk_short_kernel(RleJob* j
   __shared__ unsigned long long seen[8 * 64];
   __shared__ unsigned long long fresh[8 * 64];
   uint32_t lane = threadIdx.x;
-  uint32_t bw = blockIdx.x * 64u;
-  if (bw >= total_blocks) return;
-  RleJob* j = const_cast<RleJob*>(find_job_by_block(jobs, njobs, bw));
-  uint32_t lb0 = bw - j->block0;
-  uint32_t lb = lb0 + lane;
+  // eight spans per workgroup (block ranges of a job are RLE_TILE aligned, so all eight belong to
+  // one stream): their flags are fetched together, spans with few weak blocks cost nothing more
+  uint32_t bw8 = blockIdx.x * 512u;
+  if (bw8 >= total_blocks) return;
+  RleJob* j = const_cast<RleJob*>(find_job_by_block(jobs, njobs, bw8));
   uint64_t len = scalars[j->len_idx];
-  bool live = lb < j->nblocks && ((uint64_t)lb * RLE_BLK < len || lb == 0);
-  bool weak = live && !blk.flags[bw + lane];
-  // isolated weak blocks inside long-run streams are left to the relaxation rounds
-  if (__builtin_popcountll(__ballot(weak)) < 16) return;
-  if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live, weak);
-  else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live, weak);
-  else short_span<CODEC_BYTE>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live, weak);
+  bool live8[8], weak8[8];
+#pragma unroll
+  for (int s = 0; s < 8; s++) {
+    uint32_t lb = bw8 - j->block0 + s * 64 + lane;
+    live8[s] = lb < j->nblocks && ((uint64_t)lb * RLE_BLK < len || lb == 0);
+    weak8[s] = live8[s] && !blk.flags[bw8 + s * 64 + lane];
+  }
+#pragma unroll
+  for (int s = 0; s < 8; s++) {
+    // isolated weak blocks inside long-run streams are left to the relaxation rounds
+    if (__builtin_popcountll(__ballot(weak8[s])) < 16) continue;
+    uint32_t bw = bw8 + s * 64, lb0 = bw - j->block0;
+    if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live8[s], weak8[s]);
+    else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live8[s], weak8[s]);
+    else short_span<CODEC_BYTE>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live8[s], weak8[s]);
+    wave_sync_scan();
+  }
 }
 
 // Repair of whatever the relaxation rounds left inconsistent (long runs of irregular size never
@@ -646,7 +811,7 @@ extern "C" __global__ void __launch_bounds__(256) rle_tile_scan_kernel(RleBlocks
   if (threadIdx.x == 255) tile_sum[tile] = excl + s;
 }
 
-// Per job: exclusive scan of its tile sums -> tile_base, total -> scalars[total_idx].
+// Per job: exclusive scan of its tile sums -> tile_base, total -> scalars[total_idx]; group -> job table.
 extern "C" __global__ void __launch_bounds__(256) rle_job_scan_kernel(const RleJob* jobs, RleBlocks blk, const uint32_t* tile_sum,
                                                                        uint64_t* scalars) {
   __shared__ uint64_t wsum[4];
@@ -654,6 +819,8 @@ extern "C" __global__ void __launch_bounds__(256) rle_job_scan_kernel(const RleJ
   const RleJob* j = &jobs[blockIdx.x];
   uint32_t t0 = j->block0 / RLE_TILE;
   uint32_t nt = (j->nblocks + RLE_TILE - 1) / RLE_TILE;
+  // group -> job table of the expansion (saves every expansion wavefront a search over the jobs)
+  for (uint32_t g = threadIdx.x; g < j->ngroups; g += 256) blk.group_job[j->group_tab0 + g] = j->class_index;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   for (uint32_t s = 0; s < nt; s += 256) {
