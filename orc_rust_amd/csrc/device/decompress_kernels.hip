@@ -178,6 +178,9 @@ extern "C" __global__ void __launch_bounds__(64) decompress_chunks_kernel(ChunkD
   if (c >= n_chunks) return;
   uint32_t lane = threadIdx.x;
   ChunkDesc d = chunks[c];
+  d.src = as_global(d.src);  // plain global memory, not generic: see as_global()
+  d.dst = (uint8_t*)as_global((void*)d.dst);
+  d.scratch = (decltype(d.scratch))as_global((void*)d.scratch);
   uint32_t out_len = 0;
   int bad = 0;
   switch (d.kind) {

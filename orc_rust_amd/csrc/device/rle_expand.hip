@@ -122,8 +122,8 @@ __device__ __forceinline__ void direct_pair_load(const uint8_t* pp, uint32_t i0,
 template <int CODEC, int OB>
 __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, const uint64_t* scalars, uint32_t lg, WaveLds& L,
                                              uint32_t lane PROF_PARM) {
-  const uint8_t* data = j->data;
-  void* out = j->out;
+  const uint8_t* data = as_global(j->data);
+  void* out = as_global(j->out);
   const uint64_t len = scalars[j->len_idx];
   const uint64_t needed = scalars[j->needed_idx];
   const bool is_signed = j->is_signed;

@@ -34,6 +34,22 @@ enum : int { CODEC_RLE2 = 0, CODEC_RLE1 = 1, CODEC_BYTE = 2 };
 enum : int { RT_SR = 0, RT_DIRECT = 1, RT_PATCHED = 2, RT_DELTA = 3,   // RLE v2 sub-encodings
              RT_V1_RUN = 4, RT_V1_LIT = 5, RT_B_RUN = 6, RT_B_LIT = 7 };
 
+// Pointers read out of job structures are generic to the compiler, and generic ("flat") accesses
+// count against the LDS counter as well as the memory counter: every wait for an LDS result would
+// also wait for the stream loads and value stores in flight.  as_global() states what the host
+// knows -- the pointer is device global memory -- in a way the optimiser cannot
+// fold away: the cast to the global address space passes through an empty asm.
+__device__ __forceinline__ const uint8_t* as_global(const uint8_t* p) {
+  const __attribute__((address_space(1))) uint8_t* g = (const __attribute__((address_space(1))) uint8_t*)p;
+  asm volatile("" : "+v"(g));
+  return (const uint8_t*)g;
+}
+__device__ __forceinline__ void* as_global(void* p) {
+  __attribute__((address_space(1))) uint8_t* g = (__attribute__((address_space(1))) uint8_t*)p;
+  asm volatile("" : "+v"(g));
+  return (void*)g;
+}
+
 __device__ __forceinline__ uint64_t ld_u64(const uint8_t* p) {
   uint64_t v;
   __builtin_memcpy(&v, p, 8);
@@ -389,6 +405,53 @@ __device__ __forceinline__ void run_parse(const uint8_t* p, uint64_t avail, bool
   else byte_parse<FULL>(p, avail, h);
 }
 
+// Lean parse of an RLE v2 header out of a 24-byte window (no memory access): size and count of the
+// run.  Returns false for anything unusual (the caller then takes the full parse).
+__device__ __forceinline__ bool rle2_lean(const Win24& win, int nbits, uint32_t& sz, uint32_t& cnt) {
+  const uint32_t h0 = (uint32_t)win.w0 & 0xff, b1 = (uint32_t)(win.w0 >> 8) & 0xff;
+  const uint32_t t = h0 >> 6, enc = (h0 >> 1) & 31;
+  const uint32_t nn = (((h0 & 1) << 8) | b1) + 1;
+  bool ok = false;
+  sz = 0, cnt = 0;
+  if (t == RT_SR) {
+    uint32_t bw = ((h0 >> 3) & 7) + 1;
+    sz = 1 + bw;
+    cnt = (h0 & 7) + 3;
+    ok = bw * 8 <= (uint32_t)nbits;
+  } else if (t == RT_DIRECT) {
+    uint32_t w = rle2_width(enc);
+    sz = 2 + ((nn * w + 7) >> 3);
+    cnt = nn;
+    ok = w <= (uint32_t)nbits;
+  } else if (t == RT_PATCHED) {
+    uint32_t w = rle2_width(enc);
+    uint32_t b2 = (uint32_t)(win.w0 >> 16) & 0xff, b3 = (uint32_t)(win.w0 >> 24) & 0xff;
+    uint32_t bw = (b2 >> 5) + 1, pw = rle2_width(b2 & 31), pgw = (b3 >> 5) + 1, pl = b3 & 31;
+    uint32_t cw = closest_fixed_bits(pw + pgw);
+    sz = 4 + bw + ((nn * w + 7) >> 3) + ((pl * cw + 7) >> 3);
+    cnt = nn;
+    ok = pw + pgw <= 64 && pl != 0 && !((w & 7) == 0 && w > (uint32_t)nbits);
+  } else {
+    uint32_t w = enc == 0 ? 0 : rle2_width(enc);
+    // two varints starting at byte 2: lengths from the terminator bits of bytes 2..21
+    uint64_t v0 = win_u64(win, 2), v1 = win_u64(win, 10);
+    uint64_t t0 = ~v0 & 0x8080808080808080ull, t1 = ~v1 & 0x8080808080808080ull;
+    uint32_t l1 = t0 ? (uint32_t)(__builtin_ctzll(t0) >> 3) + 1 : (t1 ? (uint32_t)(__builtin_ctzll(t1) >> 3) + 9 : 99);
+    uint32_t maxg = (uint32_t)(nbits + 6) / 7;
+    if (l1 <= maxg && l1 <= 10) {
+      uint64_t u0 = win_u64(win, 2 + l1), u1 = win_u64(win, 10 + l1);
+      uint64_t s0 = ~u0 & 0x8080808080808080ull, s1 = ~u1 & 0x8080808080808080ull;
+      uint32_t l2 = s0 ? (uint32_t)(__builtin_ctzll(s0) >> 3) + 1 : (s1 ? (uint32_t)(__builtin_ctzll(s1) >> 3) + 9 : 99);
+      if (l2 <= 10 && 2 + l1 + l2 <= 22) {
+        sz = 2 + l1 + l2 + (w ? (((nn - 2) * w + 7) >> 3) : 0);
+        cnt = nn;
+        ok = !(w && nn < 2);
+      }
+    }
+  }
+  return ok;
+}
+
 // ---- lean hop: (size, n) of the run at p, for the block walks ------------------------------------------
 // Identical to run_parse<CODEC, false> whenever that succeeds; anything unusual (errors, the last
 // bytes of the stream) is delegated to run_parse so that both always agree.
@@ -396,48 +459,8 @@ template <int CODEC>
 __device__ __forceinline__ void hop_parse(const uint8_t* p, uint64_t avail, bool is_signed, int nbits, uint32_t& size, uint32_t& n, uint32_t& err) {
   if (CODEC == CODEC_RLE2 && avail >= 32) {
     const Win24 win = ld_win24(p);
-    const uint32_t h0 = (uint32_t)win.w0 & 0xff, b1 = (uint32_t)(win.w0 >> 8) & 0xff;
-    const uint32_t t = h0 >> 6, enc = (h0 >> 1) & 31;
-    const uint32_t nn = (((h0 & 1) << 8) | b1) + 1;
-    bool ok = false;
     uint32_t sz = 0, cnt = 0;
-    if (t == RT_SR) {
-      uint32_t bw = ((h0 >> 3) & 7) + 1;
-      sz = 1 + bw;
-      cnt = (h0 & 7) + 3;
-      ok = bw * 8 <= (uint32_t)nbits;
-    } else if (t == RT_DIRECT) {
-      uint32_t w = rle2_width(enc);
-      sz = 2 + ((nn * w + 7) >> 3);
-      cnt = nn;
-      ok = w <= (uint32_t)nbits;
-    } else if (t == RT_PATCHED) {
-      uint32_t w = rle2_width(enc);
-      uint32_t b2 = (uint32_t)(win.w0 >> 16) & 0xff, b3 = (uint32_t)(win.w0 >> 24) & 0xff;
-      uint32_t bw = (b2 >> 5) + 1, pw = rle2_width(b2 & 31), pgw = (b3 >> 5) + 1, pl = b3 & 31;
-      uint32_t cw = closest_fixed_bits(pw + pgw);
-      sz = 4 + bw + ((nn * w + 7) >> 3) + ((pl * cw + 7) >> 3);
-      cnt = nn;
-      ok = pw + pgw <= 64 && pl != 0 && !((w & 7) == 0 && w > (uint32_t)nbits);
-    } else {
-      uint32_t w = enc == 0 ? 0 : rle2_width(enc);
-      // two varints starting at byte 2: lengths from the terminator bits of bytes 2..21
-      uint64_t v0 = win_u64(win, 2), v1 = win_u64(win, 10);
-      uint64_t t0 = ~v0 & 0x8080808080808080ull, t1 = ~v1 & 0x8080808080808080ull;
-      uint32_t l1 = t0 ? (uint32_t)(__builtin_ctzll(t0) >> 3) + 1 : (t1 ? (uint32_t)(__builtin_ctzll(t1) >> 3) + 9 : 99);
-      uint32_t maxg = (uint32_t)(nbits + 6) / 7;
-      if (l1 <= maxg && l1 <= 10) {
-        uint64_t u0 = win_u64(win, 2 + l1), u1 = win_u64(win, 10 + l1);
-        uint64_t s0 = ~u0 & 0x8080808080808080ull, s1 = ~u1 & 0x8080808080808080ull;
-        uint32_t l2 = s0 ? (uint32_t)(__builtin_ctzll(s0) >> 3) + 1 : (s1 ? (uint32_t)(__builtin_ctzll(s1) >> 3) + 9 : 99);
-        if (l2 <= 10 && 2 + l1 + l2 <= 22) {
-          sz = 2 + l1 + l2 + (w ? (((nn - 2) * w + 7) >> 3) : 0);
-          cnt = nn;
-          ok = !(w && nn < 2);
-        }
-      }
-    }
-    if (ok && sz <= avail) {
+    if (rle2_lean(win, nbits, sz, cnt) && sz <= avail) {
       size = sz;
       n = cnt;
       err = 0;

@@ -186,14 +186,15 @@ __device__ __forceinline__ uint32_t wave_find_candidates(const uint8_t* data, ui
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         uint64_t p = wbase + (uint64_t)(i0 + u) * 1024 + lane * 16;
-        bool in = p < len;  // the staged stream carries ORC_PAD readable bytes past len
-        lo[u] = 0, hi[u] = 0;
-        if (in) {
-          uint64_t v[2];
-          __builtin_memcpy(v, data + p, 16);
-          lo[u] = v[0], hi[u] = v[1];
-        }
-        edge[u] = (lane == 63 && p + 16 < len) ? data[p + 16] : 0u;  // the byte after the instruction's 1 KiB
+        // branch-free (all eight loads stay in flight): out-of-range lanes read the stream's first
+        // bytes instead and discard them; the staged stream carries ORC_PAD readable bytes past len
+        const bool in = p < len;
+        uint64_t v[2];
+        __builtin_memcpy(v, data + (in ? p : 0), 16);
+        lo[u] = in ? v[0] : 0, hi[u] = in ? v[1] : 0;
+        const bool ein = lane == 63 && p + 16 < len;
+        const uint32_t eb = data[ein ? p + 16 : 0];
+        edge[u] = ein ? eb : 0u;  // the byte after the instruction's 1 KiB
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
@@ -315,7 +316,7 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
   uint64_t len = scalars[j->len_idx];
   bool in_job = lb < j->nblocks;
   bool live = in_job && ((uint64_t)lb * RLE_BLK < len || lb == 0);
-  const uint8_t* data = j->data;
+  const uint8_t* data = as_global(j->data);
   if (mode == 0) {
     if ((b & 31) == 0) blk.badmap[b >> 5] = 0;  // the verify round marks blocks here
     uint32_t want = 0, strong = 0;
@@ -419,25 +420,32 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
       fl = blk.flags[b];
     }
     uint32_t pex0 = 0, pfl0 = 0;
+    bool panc0 = false;
     if (live && lb > 0 && lane == 0) {
       pex0 = blk.exit_[b - 1];
       pfl0 = blk.flags[b - 1];
+      panc0 = lb == 1 || blk.entry[b - 1] == blk.exit_[b - 2];
     }
     bool dirty = false;
     for (int sweep = 0; sweep < 4; sweep++) {
       uint32_t pex = __shfl_up(ex, 1), pfl = __shfl_up(fl, 1);
       if (lane == 0) pex = pex0, pfl = pfl0;
+      // "anchored": the block's entry agrees with its own predecessor's exit
+      bool anchored = live && (lb == 0 || pex == e);
+      bool panc = __shfl_up((int)anchored, 1);
+      if (lane == 0) panc = panc0;
       bool change = false;
       if (live && lb > 0 && pex != e) {
-        // A strong block ignores a weak predecessor (its exit may be garbage).  A STRONG predecessor's
-        // exit always lies on the true chain -- a false candidate only passes verification by hopping
-        // onto it -- so when the two disagree this block keeps its entry only if its own chain
-        // reaches the predecessor's header exactly (then the predecessor skipped runs, not us).
+        // A strong block ignores a weak predecessor (its exit may be garbage).  Two strong neighbours
+        // that disagree: one of them holds a false candidate (it passed verification by hopping onto
+        // the true chain).  An anchored predecessor is trusted; otherwise this block keeps its entry
+        // only if its own chain reaches the predecessor's header exactly (then the predecessor
+        // skipped runs, not us).
         bool keep = false;
         if (fl) {
           if (!pfl) {
             keep = true;
-          } else if (e < pex && e < RLE_BLK) {
+          } else if (!panc && e < pex && e < RLE_BLK) {
             uint64_t from = (uint64_t)lb * RLE_BLK + e, target = (uint64_t)lb * RLE_BLK + pex;
             if (j->codec == CODEC_RLE2) keep = chain_hits<CODEC_RLE2>(data, len, from, target, j->is_signed, j->nbits);
             else if (j->codec == CODEC_RLE1) keep = chain_hits<CODEC_RLE1>(data, len, from, target, j->is_signed, j->nbits);
@@ -540,7 +548,7 @@ __device__ __forceinline__ uint32_t count_lds(const uint8_t* buf, const uint8_t*
 template <int CODEC>
 __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t lb0, uint32_t b0g, uint8_t* buf,
                                            unsigned long long* seen_all, unsigned long long* fresh_all, uint32_t lane, bool live, bool weak) {
-  const uint8_t* data = j->data;
+  const uint8_t* data = as_global(j->data);
   const bool is_signed = j->is_signed;
   const int nbits = j->nbits;
   const uint32_t wstart = lb0 >= RLE_WARM ? lb0 - RLE_WARM : 0u;
@@ -655,7 +663,7 @@ extern "C" __global__ void __launch_bounds__(64) rle_walk_short_kernel(RleJob* j
 // block is inconsistent.
 template <int CODEC>
 __device__ __forceinline__ void repair_chain(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t nb, uint32_t lane) {
-  const uint8_t* data = j->data;
+  const uint8_t* data = as_global(j->data);
   const bool is_signed = j->is_signed;
   const int nbits = j->nbits;
   const uint32_t b0 = j->block0;
