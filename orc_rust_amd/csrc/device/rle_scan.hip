@@ -348,7 +348,9 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
           const uint32_t b2 = gp < len ? (ld_u32(data + gp) & 0xffffu) : head2;
           const uint32_t mask2 = j->codec == CODEC_RLE2 ? 0xffffu : 0xffu;
           if (((a2 ^ head2) & mask2) == 0 && ((b2 ^ head2) & mask2) == 0) {
-            const bool self_sized = (j->codec == CODEC_RLE2 && h.type == RT_DIRECT) || j->codec == CODEC_BYTE;
+            // (only for runs of some length: two matching header bytes at the predicted places are
+            // evidence for a 3 KiB stride, not for a 2-byte one -- 0xff 0xff is everywhere in a bitmap)
+            const bool self_sized = ((j->codec == CODEC_RLE2 && h.type == RT_DIRECT) || j->codec == CODEC_BYTE) && s0 >= 64;
             if (self_sized && !h.err) {
               ok = true;
             } else {
@@ -517,7 +519,7 @@ __device__ __forceinline__ void hop_lds(const uint8_t* buf, const uint8_t* data,
 // once the entries have converged.
 template <int CODEC>
 __device__ __forceinline__ void walk_lds(const uint8_t* buf, const uint8_t* data, uint64_t gstart, uint64_t gend, uint64_t len, uint32_t lbv,
-                                         uint32_t entry, bool is_signed, int nbits, unsigned long long*, unsigned long long*, uint32_t* exit_io) {
+                                         uint32_t entry, bool is_signed, int nbits, uint32_t* exit_io) {
   const uint64_t bend = (uint64_t)(lbv + 1) * RLE_BLK;
   const uint64_t end = bend < len ? bend : len;
   uint64_t pos = (uint64_t)lbv * RLE_BLK + entry;
@@ -546,8 +548,8 @@ __device__ __forceinline__ uint32_t count_lds(const uint8_t* buf, const uint8_t*
 }
 
 template <int CODEC>
-__device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t lb0, uint32_t b0g, uint8_t* buf,
-                                           unsigned long long* seen_all, unsigned long long* fresh_all, uint32_t lane, bool live, bool weak) {
+__device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t lb0, uint32_t b0g, uint8_t* buf, uint32_t lane,
+                                           bool live, bool weak PROF_PARM) {
   const uint8_t* data = as_global(j->data);
   const bool is_signed = j->is_signed;
   const int nbits = j->nbits;
@@ -556,8 +558,6 @@ __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint
   const uint64_t gstart = (uint64_t)wstart * RLE_BLK;
   uint64_t gend = (uint64_t)(lb0 + 64) * RLE_BLK + ORC_PAD;
   if (gend > len + ORC_PAD) gend = len + ORC_PAD;
-  unsigned long long* seen = seen_all + lane;
-  unsigned long long* fresh = fresh_all + lane;
   // stage the bytes (coalesced 16-byte pieces)
   for (uint64_t o0 = (uint64_t)lane * 16; gstart + o0 < gend; o0 += 8 * 64 * 16) {
     uint4 v[8];
@@ -572,8 +572,8 @@ __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint
       if (gstart + o < gend) __builtin_memcpy(buf + o, &v[u], 16);
     }
   }
-  for (int k = 0; k < 8; k++) seen[k * 64] = 0;
   wave_sync_scan();
+  PROF_MARK(5);
   uint32_t E = 0;
   const bool first_weak = __shfl((int)weak, 0);
   if (nwarm > 0 && first_weak) {
@@ -581,7 +581,10 @@ __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint
     uint32_t e = 0, ex = 0;
     bool dirty = lane < nwarm;
     for (int it = 0; it < 64; it++) {
-      if (dirty) walk_lds<CODEC>(buf, data, gstart, gend, len, wstart + lane, e, is_signed, nbits, seen, fresh, &ex);
+#ifdef ORC_PROF
+      if (lane == 0) atomicAdd(&g_prof[40], 1ull);
+#endif
+      if (dirty) walk_lds<CODEC>(buf, data, gstart, gend, len, wstart + lane, e, is_signed, nbits, &ex);
       uint32_t prev = __shfl_up(ex, 1);
       uint32_t ne = (lane == 0 || lane >= nwarm) ? e : prev;
       dirty = ne != e;
@@ -589,20 +592,22 @@ __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint
       if (!__ballot(dirty)) break;
     }
     E = __shfl(ex, nwarm - 1);
-    for (int k = 0; k < 8; k++) seen[k * 64] = 0;
   }
+  PROF_MARK(6);
   // span phase
   uint32_t b = b0g + lane;
   uint32_t e = 0, ex = 0;
   if (live) e = weak ? (lane == 0 ? (lb0 == 0 ? 0u : E) : 0u) : blk.entry[b];
   bool dirty = live;
   for (int it = 0; it < 96; it++) {
+#ifdef ORC_PROF
+    if (lane == 0) atomicAdd(&g_prof[41], 1ull);
+#endif
     if (dirty) {
       if (e >= RLE_BLK) {
         ex = e - RLE_BLK;
-        for (int k = 0; k < 8; k++) seen[k * 64] = 0;
       } else {
-        walk_lds<CODEC>(buf, data, gstart, gend, len, lb0 + lane, e, is_signed, nbits, seen, fresh, &ex);
+        walk_lds<CODEC>(buf, data, gstart, gend, len, lb0 + lane, e, is_signed, nbits, &ex);
       }
     }
     uint32_t prev = __shfl_up(ex, 1);
@@ -611,6 +616,7 @@ __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint
     e = ne;
     if (!__ballot(dirty)) break;
   }
+  PROF_MARK(7);
   if (live && weak) {
     uint32_t nv = e >= RLE_BLK ? 0u : count_lds<CODEC>(buf, data, gstart, gend, len, lb0 + lane, e, is_signed, nbits);
     blk.entry[b] = e;
@@ -620,22 +626,24 @@ __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint
 }
 
 extern "C" __global__ void __launch_bounds__(64) rle_walk_short_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
-                                                                        uint32_t total_blocks) {
+                                                                        uint32_t total_blocks, uint32_t spans_per_wg) {
   __shared__ __attribute__((aligned(16))) uint8_t buf[(64 + RLE_WARM) * RLE_BLK + 2 * ORC_PAD];
-  __shared__ unsigned long long seen[8 * 64];
-  __shared__ unsigned long long fresh[8 * 64];
   uint32_t lane = threadIdx.x;
-  // eight spans per workgroup (block ranges of a job are RLE_TILE aligned, so all eight belong to
-  // one stream): their flags are fetched together, spans with few weak blocks cost nothing more
-  uint32_t bw8 = blockIdx.x * 512u;
+  // up to eight spans per workgroup (the host picks a power of two; block ranges of a job are
+  // RLE_TILE aligned, so they belong to one stream): their flags are fetched together, spans with
+  // few weak blocks cost nothing more.  Big batches of long-run streams have thousands of spans
+  // with nothing to do -- fewer, larger workgroups keep their dispatch cheap; small batches of
+  // short-run streams get one span per workgroup so that the spans run side by side.
+  uint32_t bw8 = blockIdx.x * 64u * spans_per_wg;
   if (bw8 >= total_blocks) return;
+  PROF_BEGIN();
   RleJob* j = const_cast<RleJob*>(find_job_by_block(jobs, njobs, bw8));
   uint64_t len = scalars[j->len_idx];
   bool live8[8], weak8[8];
 #pragma unroll
   for (int s = 0; s < 8; s++) {
     uint32_t lb = bw8 - j->block0 + s * 64 + lane;
-    live8[s] = lb < j->nblocks && ((uint64_t)lb * RLE_BLK < len || lb == 0);
+    live8[s] = (uint32_t)s < spans_per_wg && lb < j->nblocks && ((uint64_t)lb * RLE_BLK < len || lb == 0);
     weak8[s] = live8[s] && !blk.flags[bw8 + s * 64 + lane];
   }
 #pragma unroll
@@ -643,11 +651,16 @@ extern "C" __global__ void __launch_bounds__(64) rle_walk_short_kernel(RleJob* j
     // isolated weak blocks inside long-run streams are left to the relaxation rounds
     if (__builtin_popcountll(__ballot(weak8[s])) < 16) continue;
     uint32_t bw = bw8 + s * 64, lb0 = bw - j->block0;
-    if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live8[s], weak8[s]);
-    else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live8[s], weak8[s]);
-    else short_span<CODEC_BYTE>(j, blk, len, lb0, bw, buf, seen, fresh, lane, live8[s], weak8[s]);
+    if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, buf, lane, live8[s], weak8[s] PROF_ARG);
+    else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, buf, lane, live8[s], weak8[s] PROF_ARG);
+    else short_span<CODEC_BYTE>(j, blk, len, lb0, bw, buf, lane, live8[s], weak8[s] PROF_ARG);
     wave_sync_scan();
+#ifdef ORC_PROF
+    if (lane == 0) atomicAdd(&g_prof[42], 1ull);
+#endif
+    PROF_MARK(8);
   }
+  PROF_END();
 }
 
 // Repair of whatever the relaxation rounds left inconsistent (long runs of irregular size never
