@@ -35,6 +35,10 @@ struct StreamDesc {
 };
 
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+__device__ __forceinline__ void lds_order() {  // LDS accesses of one wavefront execute in order; this only pins the compiler
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ void st_u64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 
@@ -65,107 +69,238 @@ __device__ __forceinline__ void wave_match(uint8_t* dst, uint64_t out, uint32_t 
   }
 }
 
+// ---- output window in LDS ---------------------------------------------------------------------------------
+// A match that reads what the same wavefront stored a moment ago would need the stores to reach
+// L2 and a fence before every match (microseconds per token).  Instead the most recent LZ_RING
+// bytes of the output live in an LDS ring: literals and matches are written there, matches read
+// from there (LDS accesses of one wavefront are in order), and the ring is flushed to the chunk's
+// slot in HBM in 4 KiB pieces of coalesced stores.  Only a match that reaches further back than the
+// ring goes to memory (flush + fence first).
+#define LZ_RING 32768u
+#define LZ_FLUSH 4096u
+#define LZ_STAGE 4096u
+struct LzLds {
+  uint8_t ring[LZ_RING];
+  uint8_t stage[LZ_STAGE + 16];
+};
+struct LzOut {
+  uint8_t* ring;     // LDS
+  uint8_t* dst;      // the chunk's output slot
+  uint64_t out;      // bytes produced
+  uint64_t flushed;  // bytes already in dst
+};
+__device__ __forceinline__ void lz_flush(LzOut& o, uint32_t lane) {
+  lds_order();
+  const uint32_t n = (uint32_t)(o.out - o.flushed);
+  for (uint32_t k = lane * 8; k < n; k += 512) {
+    const uint32_t ri = (uint32_t)(o.flushed + k) & (LZ_RING - 1);
+    if (k + 8 <= n && ri + 8 <= LZ_RING) {
+      uint64_t v;
+      __builtin_memcpy(&v, o.ring + ri, 8);
+      st_u64(o.dst + o.flushed + k, v);
+    } else {
+      for (uint32_t t = k; t < n && t < k + 8; t++) o.dst[o.flushed + t] = o.ring[(uint32_t)(o.flushed + t) & (LZ_RING - 1)];
+    }
+  }
+  o.flushed = o.out;
+}
+__device__ __forceinline__ void lz_maybe_flush(LzOut& o, uint32_t lane) {
+  if (o.out - o.flushed >= LZ_FLUSH) lz_flush(o, lane);
+}
+// one byte (DEFLATE / Huffman literals)
+__device__ __forceinline__ void lz_byte(LzOut& o, uint32_t b, uint32_t lane) {
+  if (lane == 0) o.ring[(uint32_t)o.out & (LZ_RING - 1)] = (uint8_t)b;
+  o.out++;
+  lz_maybe_flush(o, lane);
+}
+// len literal bytes from src (global memory or LDS, not the ring)
+__device__ __forceinline__ void lz_literal(LzOut& o, const uint8_t* src, uint32_t len, uint32_t lane) {
+  for (uint32_t done = 0; done < len;) {
+    const uint32_t piece = len - done < LZ_FLUSH ? len - done : LZ_FLUSH;
+    for (uint32_t k = lane; k < piece; k += 64) o.ring[(uint32_t)(o.out + k) & (LZ_RING - 1)] = src[done + k];
+    o.out += piece;
+    done += piece;
+    lz_maybe_flush(o, lane);
+  }
+}
+// len copies of one byte (Zstandard RLE blocks)
+__device__ __forceinline__ void lz_fill(LzOut& o, uint32_t v, uint32_t len, uint32_t lane) {
+  for (uint32_t done = 0; done < len;) {
+    const uint32_t piece = len - done < LZ_FLUSH ? len - done : LZ_FLUSH;
+    for (uint32_t k = lane; k < piece; k += 64) o.ring[(uint32_t)(o.out + k) & (LZ_RING - 1)] = (uint8_t)v;
+    o.out += piece;
+    done += piece;
+    lz_maybe_flush(o, lane);
+  }
+}
+// len bytes from `off` bytes back (1 <= off <= out)
+__device__ __forceinline__ void lz_match(LzOut& o, uint32_t off, uint32_t len, uint32_t lane) {
+  lds_order();
+  for (uint32_t done = 0; done < len;) {
+    const uint32_t piece = len - done < LZ_FLUSH ? len - done : LZ_FLUSH;
+    if (off <= LZ_RING - 2 * LZ_FLUSH) {
+      // the source is still in the ring (at most LZ_FLUSH + piece unflushed bytes are ahead of it)
+      for (uint32_t k = lane; k < piece; k += 64) {
+        const uint32_t s = off >= piece ? k : k % off;
+        o.ring[(uint32_t)(o.out + k) & (LZ_RING - 1)] = o.ring[(uint32_t)(o.out - off + s) & (LZ_RING - 1)];
+      }
+    } else {
+      // far match: everything produced so far goes to memory first, then the bytes come from there
+      if (o.flushed != o.out) lz_flush(o, lane);
+      wave_fence();
+      for (uint32_t k = lane; k < piece; k += 64) {
+        const uint32_t s = off >= piece ? k : k % off;
+        o.ring[(uint32_t)(o.out + k) & (LZ_RING - 1)] = o.dst[o.out - off + s];
+      }
+    }
+    lds_order();
+    o.out += piece;
+    done += piece;
+    lz_maybe_flush(o, lane);
+  }
+}
+
+// ---- staged input: the token stream is parsed out of LDS ------------------------------------------------
+struct LzIn {
+  const uint8_t* src;
+  uint32_t n;
+  uint8_t* stage;  // LDS, LZ_STAGE + 16 bytes
+  uint32_t sb;     // stage holds src[sb, sb + LZ_STAGE) (clipped at n; zero behind it)
+};
+__device__ __forceinline__ void lzin_stage(LzIn& in, uint32_t pos, uint32_t lane) {
+  lds_order();
+  in.sb = pos;
+  for (uint32_t k = lane * 16; k < LZ_STAGE + 16; k += 1024) {
+    uint64_t v[2] = {0, 0};
+    if ((uint64_t)pos + k + 16 <= in.n) {
+      __builtin_memcpy(v, in.src + pos + k, 16);
+    } else {
+      for (uint32_t t = 0; t < 16; t++)
+        if ((uint64_t)pos + k + t < in.n) reinterpret_cast<uint8_t*>(v)[t] = in.src[pos + k + t];
+    }
+    __builtin_memcpy(in.stage + k, v, 16);
+  }
+  lds_order();
+}
+// 8 bytes at pos (zero beyond n); restages when the window does not hold them
+__device__ __forceinline__ uint64_t lzin_peek(LzIn& in, uint32_t pos, uint32_t lane) {
+  if (pos < in.sb || pos + 8 > in.sb + LZ_STAGE + 16) lzin_stage(in, pos, lane);
+  uint64_t v;
+  __builtin_memcpy(&v, in.stage + (pos - in.sb), 8);
+  return v;
+}
+__device__ __forceinline__ void lzin_literal(LzIn& in, LzOut& o, uint32_t pos, uint32_t len, uint32_t lane) {
+  if (pos >= in.sb && pos + len <= in.sb + LZ_STAGE + 16) lz_literal(o, in.stage + (pos - in.sb), len, lane);
+  else lz_literal(o, in.src + pos, len, lane);
+}
+
 // ---- Snappy raw (compression.rs:161-172) --------------------------------------------------------------
-__device__ __forceinline__ int snappy_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t lane, uint32_t* out_len) {
+__device__ __forceinline__ int snappy_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t lane, uint32_t* out_len, LzLds& Z) {
+  LzIn in{src, n, Z.stage, 0};
+  lzin_stage(in, 0, lane);
   uint32_t pos = 0;
   uint64_t ulen = 0;
   int shift = 0;
   for (;;) {
     if (pos >= n || shift > 28) return 1;
-    uint32_t c = src[pos++];
+    uint32_t c = (uint32_t)lzin_peek(in, pos, lane) & 0xff;
+    pos++;
     ulen |= (uint64_t)(c & 0x7f) << shift;
     shift += 7;
     if (!(c & 0x80)) break;
   }
   if (ulen > cap) return 1;
-  uint64_t out = 0;
+  LzOut o{Z.ring, dst, 0, 0};
   while (pos < n) {
-    uint32_t tag = src[pos++];
+    const uint64_t w = lzin_peek(in, pos, lane);  // tag + up to 4 more bytes (zero behind the end)
+    const uint32_t tag = (uint32_t)w & 0xff;
+    pos++;
     uint32_t len, off;
-    uint32_t t = tag & 3;
+    const uint32_t t = tag & 3;
     if (t == 0) {
       len = tag >> 2;
       if (len >= 60) {
         uint32_t nb = len - 59;
         if (pos + nb > n) return 1;
-        len = 0;
-        for (uint32_t i = 0; i < nb; i++) len |= (uint32_t)src[pos + i] << (8 * i);
+        len = (uint32_t)((w >> 8) & (nb == 4 ? 0xffffffffull : ((1ull << (8 * nb)) - 1)));
         pos += nb;
       }
+      if (len == 0xffffffffu) return 1;
       len += 1;
-      if ((uint64_t)pos + len > n || out + len > ulen) return 1;
-      wave_copy(dst + out, src + pos, len, lane);
+      if ((uint64_t)pos + len > n || o.out + len > ulen) return 1;
+      lzin_literal(in, o, pos, len, lane);
       pos += len;
-      out += len;
       continue;
     }
     if (t == 1) {
       if (pos + 1 > n) return 1;
       len = 4 + ((tag >> 2) & 7);
-      off = ((tag >> 5) << 8) | src[pos];
+      off = ((tag >> 5) << 8) | ((uint32_t)(w >> 8) & 0xff);
       pos += 1;
     } else if (t == 2) {
       if (pos + 2 > n) return 1;
       len = 1 + (tag >> 2);
-      off = src[pos] | ((uint32_t)src[pos + 1] << 8);
+      off = (uint32_t)(w >> 8) & 0xffff;
       pos += 2;
     } else {
       if (pos + 4 > n) return 1;
       len = 1 + (tag >> 2);
-      off = ld_u32(src + pos);
+      off = (uint32_t)(w >> 8);
       pos += 4;
     }
-    if (off == 0 || off > out || out + len > ulen) return 1;
-    wave_fence();
-    wave_match(dst, out, off, len, lane);
-    out += len;
+    if (off == 0 || off > o.out || o.out + len > ulen) return 1;
+    lz_match(o, off, len, lane);
   }
-  if (out != ulen) return 1;
-  *out_len = (uint32_t)out;
+  if (o.out != ulen) return 1;
+  lz_flush(o, lane);
+  *out_len = (uint32_t)o.out;
   return 0;
 }
 
 // ---- LZ4 block (compression.rs:185-195) ------------------------------------------------------------------
-__device__ __forceinline__ int lz4_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t lane, uint32_t* out_len) {
+__device__ __forceinline__ int lz4_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t lane, uint32_t* out_len, LzLds& Z) {
   if (n == 0) return 1;
+  LzIn in{src, n, Z.stage, 0};
+  lzin_stage(in, 0, lane);
+  LzOut o{Z.ring, dst, 0, 0};
   uint32_t pos = 0;
-  uint64_t out = 0;
   for (;;) {
     if (pos >= n) return 1;
-    uint32_t tok = src[pos++];
+    const uint32_t tok = (uint32_t)lzin_peek(in, pos, lane) & 0xff;
+    pos++;
     uint32_t lit = tok >> 4;
     if (lit == 15) {
       uint32_t c;
       do {
         if (pos >= n) return 1;
-        c = src[pos++];
+        c = (uint32_t)lzin_peek(in, pos, lane) & 0xff;
+        pos++;
         lit += c;
       } while (c == 255);
     }
-    if ((uint64_t)pos + lit > n || out + lit > cap) return 1;
-    wave_copy(dst + out, src + pos, lit, lane);
+    if ((uint64_t)pos + lit > n || o.out + lit > cap) return 1;
+    lzin_literal(in, o, pos, lit, lane);
     pos += lit;
-    out += lit;
     if (pos == n) break;
     if (pos + 2 > n) return 1;
-    uint32_t off = src[pos] | ((uint32_t)src[pos + 1] << 8);
+    const uint32_t off = (uint32_t)lzin_peek(in, pos, lane) & 0xffff;
     pos += 2;
     uint32_t ml = tok & 15;
     if (ml == 15) {
       uint32_t c;
       do {
         if (pos >= n) return 1;
-        c = src[pos++];
+        c = (uint32_t)lzin_peek(in, pos, lane) & 0xff;
+        pos++;
         ml += c;
       } while (c == 255);
     }
     ml += 4;
-    if (off == 0 || off > out || out + ml > cap) return 1;
-    wave_fence();
-    wave_match(dst, out, off, ml, lane);
-    out += ml;
+    if (off == 0 || off > o.out || o.out + ml > cap) return 1;
+    lz_match(o, off, ml, lane);
   }
-  *out_len = (uint32_t)out;
+  lz_flush(o, lane);
+  *out_len = (uint32_t)o.out;
   return 0;
 }
 
@@ -174,6 +309,7 @@ __device__ __forceinline__ int lz4_wave(const uint8_t* src, uint32_t n, uint8_t*
 
 extern "C" __global__ void __launch_bounds__(64) decompress_chunks_kernel(ChunkDesc* chunks, uint32_t n_chunks) {
   __shared__ DecompLds lds;
+  __shared__ __attribute__((aligned(16))) LzLds lz;
   uint32_t c = blockIdx.x;
   if (c >= n_chunks) return;
   uint32_t lane = threadIdx.x;
@@ -191,10 +327,10 @@ extern "C" __global__ void __launch_bounds__(64) decompress_chunks_kernel(ChunkD
         out_len = d.src_len;
       }
       break;
-    case 1: bad = inflate_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, lds); break;
-    case 2: bad = snappy_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len); break;
-    case 4: bad = lz4_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len); break;
-    case 5: bad = zstd_wave(d.src, d.src_len, d.dst, d.dst_cap, d.scratch, lane, &out_len, lds); break;
+    case 1: bad = inflate_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, lds, lz); break;
+    case 2: bad = snappy_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, lz); break;
+    case 4: bad = lz4_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, lz); break;
+    case 5: bad = zstd_wave(d.src, d.src_len, d.dst, d.dst_cap, d.scratch, lane, &out_len, lds, lz); break;
     default: bad = 1;
   }
   if (lane == 0) {

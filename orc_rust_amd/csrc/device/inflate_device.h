@@ -136,15 +136,14 @@ __device__ const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 
 __device__ const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ const uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-__device__ __forceinline__ int inflate_codes_dev(BitRd& b, uint8_t* dst, uint32_t cap, uint64_t& out, const HuffTab& lc, const HuffTab& dc,
+__device__ __forceinline__ int inflate_codes_dev(BitRd& b, LzOut& o, uint32_t cap, const HuffTab& lc, const HuffTab& dc,
                                                   uint32_t lane) {
   for (;;) {
     int sym = huff_decode_dev(b, lc);
     if (sym < 0) return 1;
     if (sym < 256) {
-      if (out >= cap) return 1;
-      if (lane == 0) dst[out] = (uint8_t)sym;
-      out++;
+      if (o.out >= cap) return 1;
+      lz_byte(o, (uint32_t)sym, lane);
     } else if (sym == 256) {
       return br_overrun(b) ? 1 : 0;
     } else {
@@ -154,19 +153,17 @@ __device__ __forceinline__ int inflate_codes_dev(BitRd& b, uint8_t* dst, uint32_
       int ds = huff_decode_dev(b, dc);
       if (ds < 0 || ds >= 30) return 1;
       uint32_t dist = DBASE[ds] + br_get(b, DEXT[ds]);
-      if (dist > out || out + len > cap) return 1;
-      wave_fence();
-      wave_match(dst, out, dist, len, lane);
-      out += len;
+      if (dist > o.out || o.out + len > cap) return 1;
+      lz_match(o, dist, len, lane);
     }
     if (br_overrun(b)) return 1;
   }
 }
 
 __device__ __forceinline__ int inflate_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t lane, uint32_t* out_len,
-                                             DecompLds& L) {
+                                             DecompLds& L, LzLds& Z) {
   BitRd b{src, n, 0, 0, 0};
-  uint64_t out = 0;
+  LzOut o{Z.ring, dst, 0, 0};
   uint32_t last;
   do {
     last = br_get(b, 1);
@@ -183,9 +180,8 @@ __device__ __forceinline__ int inflate_wave(const uint8_t* src, uint32_t n, uint
       uint32_t nlen = src[bytepos + 2] | (src[bytepos + 3] << 8);
       bytepos += 4;
       if ((len ^ 0xffffu) != nlen) return 1;
-      if (bytepos + len > n || out + len > cap) return 1;
-      wave_copy(dst + out, src + bytepos, len, lane);
-      out += len;
+      if (bytepos + len > n || o.out + len > cap) return 1;
+      lz_literal(o, src + bytepos, len, lane);
       b.pos = bytepos + len;
       b.bb = 0;
       b.bc = 0;
@@ -196,7 +192,7 @@ __device__ __forceinline__ int inflate_wave(const uint8_t* src, uint32_t n, uint
       for (uint32_t i = lane; i < 30; i += 64) L.inf.lens[i] = 5;
       wave_sync();
       huff_build_dev(L.inf.dist, L.inf.lens, 30, lane);
-      if (inflate_codes_dev(b, dst, cap, out, L.inf.lit, L.inf.dist, lane)) return 1;
+      if (inflate_codes_dev(b, o, cap, L.inf.lit, L.inf.dist, lane)) return 1;
     } else if (type == 2) {
       uint32_t nlen = br_get(b, 5) + 257, ndist = br_get(b, 5) + 1, ncode = br_get(b, 4) + 4;
       if (br_overrun(b) || nlen > 286 || ndist > 30) return 1;
@@ -255,11 +251,12 @@ __device__ __forceinline__ int inflate_wave(const uint8_t* src, uint32_t n, uint
       if (r < 0 || (r > 0 && (int)ndist - (int)L.inf.dist.count[0] != 1)) return 1;
       r = huff_build_dev(L.inf.lit, L.inf.lens, (int)nlen, lane);
       if (r < 0 || (r > 0 && (int)nlen - (int)L.inf.lit.count[0] != 1)) return 1;
-      if (inflate_codes_dev(b, dst, cap, out, L.inf.lit, L.inf.dist, lane)) return 1;
+      if (inflate_codes_dev(b, o, cap, L.inf.lit, L.inf.dist, lane)) return 1;
     } else {
       return 1;
     }
   } while (!last);
-  *out_len = (uint32_t)out;
+  lz_flush(o, lane);
+  *out_len = (uint32_t)o.out;
   return 0;
 }

@@ -406,7 +406,8 @@ __device__ __forceinline__ long z_seq_table_dev(FseEnt* t, int* valid, int* log_
 }
 
 // one compressed block; returns the new output size or -1
-__device__ __forceinline__ long z_block_dev(ZState& z, DecompLds& L, const uint8_t* p, uint32_t n, uint8_t* dst, uint64_t cap, uint64_t out,
+// (returns 0 or -1; the output goes through the LDS window `o`; match distances count from frame_start)
+__device__ __forceinline__ long z_block_dev(ZState& z, DecompLds& L, const uint8_t* p, uint32_t n, LzOut& o, uint64_t frame_start, uint64_t cap,
                                             uint8_t* scratch, uint32_t lane) {
   const uint8_t* lit = nullptr;
   uint32_t litn = 0;
@@ -481,14 +482,11 @@ __device__ __forceinline__ long z_block_dev(ZState& z, DecompLds& L, const uint8
         }
       }
       if (offset == 0) return -1;
-      if ((uint64_t)lp + llen > litn || out + llen + mlen > cap) return -1;
-      wave_copy(dst + out, lit + lp, llen, lane);
+      if ((uint64_t)lp + llen > litn || o.out + llen + mlen > cap) return -1;
+      lz_literal(o, lit + lp, llen, lane);
       lp += llen;
-      out += llen;
-      if (offset > out) return -1;
-      wave_fence();
-      wave_match(dst, out, (uint32_t)offset, mlen, lane);
-      out += mlen;
+      if (offset > o.out - frame_start) return -1;
+      lz_match(o, (uint32_t)offset, mlen, lane);
       if (i + 1 < nseq) {
         sl = el.base + (uint32_t)rb_read(r, el.nb);
         sm = em.base + (uint32_t)rb_read(r, em.nb);
@@ -498,17 +496,15 @@ __device__ __forceinline__ long z_block_dev(ZState& z, DecompLds& L, const uint8
     }
     if (r.bits != 0) return -1;
   }
-  if (out + (litn - lp) > cap) return -1;
-  wave_copy(dst + out, lit + lp, litn - lp, lane);
-  out += litn - lp;
-  wave_fence();
-  return (long)out;
+  if (o.out + (litn - lp) > cap) return -1;
+  lz_literal(o, lit + lp, litn - lp, lane);
+  return 0;
 }
 
 __device__ __forceinline__ int zstd_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* scratch, uint32_t lane,
-                                          uint32_t* out_len, DecompLds& L) {
+                                          uint32_t* out_len, DecompLds& L, LzLds& Z) {
   uint32_t pos = 0;
-  uint64_t out = 0;
+  LzOut o{Z.ring, dst, 0, 0};
   while (pos < n) {
     if (pos + 4 > n) return 1;
     uint32_t magic = ld_u32(src + pos);
@@ -543,7 +539,7 @@ __device__ __forceinline__ int zstd_wave(const uint8_t* src, uint32_t n, uint8_t
     for (uint32_t i = 0; i < fcs_bytes; i++) fcs |= (uint64_t)src[pos + i] << (8 * i);
     if (fcs_bytes == 2) fcs += 256;
     pos += fcs_bytes;
-    uint64_t frame_start = out;
+    uint64_t frame_start = o.out;
     ZState z;
     z.huf_valid = z.ll_valid = z.of_valid = z.ml_valid = 0;
     z.huf_bits = z.ll_log = z.of_log = z.ml_log = 0;
@@ -558,33 +554,28 @@ __device__ __forceinline__ int zstd_wave(const uint8_t* src, uint32_t n, uint8_t
       last = bh & 1;
       uint32_t bt = (bh >> 1) & 3, bs = bh >> 3;
       if (bt == 0) {
-        if ((uint64_t)pos + bs > n || out + bs > cap) return 1;
-        wave_copy(dst + out, src + pos, bs, lane);
+        if ((uint64_t)pos + bs > n || o.out + bs > cap) return 1;
+        lz_literal(o, src + pos, bs, lane);
         pos += bs;
-        out += bs;
       } else if (bt == 1) {
-        if (pos + 1 > n || out + bs > cap) return 1;
-        uint8_t v = src[pos];
-        for (uint32_t k = lane; k < bs; k += 64) dst[out + k] = v;
+        if (pos + 1 > n || o.out + bs > cap) return 1;
+        lz_fill(o, src[pos], bs, lane);
         pos += 1;
-        out += bs;
       } else if (bt == 2) {
         if ((uint64_t)pos + bs > n || bs > 128 * 1024) return 1;
-        long r = z_block_dev(z, L, src + pos, bs, dst + frame_start, cap - frame_start, out - frame_start, scratch, lane);
-        if (r < 0) return 1;
-        out = frame_start + (uint64_t)r;
+        if (z_block_dev(z, L, src + pos, bs, o, frame_start, cap, scratch, lane) < 0) return 1;
         pos += bs;
       } else {
         return 1;
       }
-      wave_fence();
     } while (!last);
-    if (fcs_bytes && out - frame_start != fcs) return 1;
+    if (fcs_bytes && o.out - frame_start != fcs) return 1;
     if (has_ck) {
       if (pos + 4 > n) return 1;
       pos += 4;
     }
   }
-  *out_len = (uint32_t)out;
+  lz_flush(o, lane);
+  *out_len = (uint32_t)o.out;
   return 0;
 }
