@@ -161,9 +161,9 @@ __device__ __forceinline__ int inflate_codes_dev(BitRd& b, LzOut& o, uint32_t ca
 }
 
 __device__ __forceinline__ int inflate_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t lane, uint32_t* out_len,
-                                             DecompLds& L, LzLds& Z) {
+                                             DecompLds& L, LzLds Z) {
   BitRd b{src, n, 0, 0, 0};
-  LzOut o{Z.ring, dst, 0, 0};
+  LzOut o{Z.ring, Z.rsize - 1, dst, 0, 0};
   uint32_t last;
   do {
     last = br_get(b, 1);

@@ -502,9 +502,9 @@ __device__ __forceinline__ long z_block_dev(ZState& z, DecompLds& L, const uint8
 }
 
 __device__ __forceinline__ int zstd_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* scratch, uint32_t lane,
-                                          uint32_t* out_len, DecompLds& L, LzLds& Z) {
+                                          uint32_t* out_len, DecompLds& L, LzLds Z) {
   uint32_t pos = 0;
-  LzOut o{Z.ring, dst, 0, 0};
+  LzOut o{Z.ring, Z.rsize - 1, dst, 0, 0};
   while (pos < n) {
     if (pos + 4 > n) return 1;
     uint32_t magic = ld_u32(src + pos);
