@@ -288,11 +288,29 @@ __device__ __forceinline__ int lz_group_run(LzGroup& G, LzIn& in, LzOut& o, uint
   lds_order();
   PROF_MARK(1);
   if (act && !later) {
+    // eight bytes per step while neither side wraps around the ring (a match needs off >= 8 for that)
+    const uint32_t d0 = (uint32_t)my & o.rmask;
+    uint32_t k = 0;
     if (lit) {
       const uint8_t* s = in.stage + (G.src - in.sb);
-      for (uint32_t k = 0; k < len; k++) o.ring[(uint32_t)(my + k) & o.rmask] = s[k];
+      if (d0 + len <= o.rmask + 1) {
+        for (; k + 8 <= len; k += 8) {
+          uint64_t v;
+          __builtin_memcpy(&v, s + k, 8);
+          __builtin_memcpy(o.ring + d0 + k, &v, 8);
+        }
+      }
+      for (; k < len; k++) o.ring[(uint32_t)(my + k) & o.rmask] = s[k];
     } else {
-      for (uint32_t k = 0; k < len; k++) {
+      const uint32_t s0 = (uint32_t)(my - G.off) & o.rmask;
+      if (G.off >= 8 && d0 + len <= o.rmask + 1 && s0 + len <= o.rmask + 1) {
+        for (; k + 8 <= len; k += 8) {
+          uint64_t v;
+          __builtin_memcpy(&v, o.ring + s0 + k, 8);
+          __builtin_memcpy(o.ring + d0 + k, &v, 8);
+        }
+      }
+      for (; k < len; k++) {
         const uint32_t sidx = len <= G.off ? k : k % G.off;
         o.ring[(uint32_t)(my + k) & o.rmask] = o.ring[(uint32_t)(my - G.off + sidx) & o.rmask];
       }
@@ -398,14 +416,21 @@ __device__ __forceinline__ int snappy_wave(const uint8_t* src, uint32_t n, uint8
     // ---- follow the chain from lane 0 ----
     unsigned long long members = 0;
     uint32_t cur = 0, stop = 0;
-    while (cur < 64) {
-      const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hop, (int)cur);
+    {
+      // (one short basic block per hop -- taken branches are what a lone wavefront pays most for: a
+      // flagged lane's hop is >= 65536, which ends the loop by itself and is undone afterwards)
+      uint32_t last = 0, h = 0;
+      while (cur < 64) {
+        h = (uint32_t)__builtin_amdgcn_readlane((int)hop, (int)cur);
+        members |= 1ull << cur;
+        last = cur;
+        cur += h;
+      }
       if (h >> 16) {
         stop = h >> 16;
-        break;
+        members &= ~(1ull << last);
+        cur = last;
       }
-      members |= 1ull << cur;
-      cur += h;
     }
     PROF_MARK(7);
     // ---- members -> group table (stream order = lane order) ----
