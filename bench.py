@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS_TOTAL)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kind", default="mix", choices=["mix", "direct", "delta", "arange"], help="mix = the headline 50/50 workload")
+    ap.add_argument("--skip-check", action="store_true", help="profiling runs: skip the full-size parity properties (12 k small D2H copies)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,7 +117,11 @@ def main():
     ctx = capi.Context(local_rank)
     stripes = build_workload(args.rows, STRIPE_ROWS, args.kind)
     cols = [{"column_id": 1, "orc_type": 4, "encoding": 2}]
+    torch.cuda.synchronize()
+    t_stage = time.perf_counter()
     staged = [ctx.stage(st["n"], [(1, 1, st["stream"])], cols) for st in stripes]
+    torch.cuda.synchronize()
+    t_stage = time.perf_counter() - t_stage  # host buffers -> HBM through the pinned bounce buffer (not part of `value`)
     stream_bytes = sum(s.nbytes() for s in staged)
     rows = sum(st["n"] for st in stripes)
 
@@ -129,6 +134,8 @@ def main():
     # parity properties at full size (size independent): first values, xor and wrapping sum per stripe
     for st, res in zip(stripes, results):
         assert res.status()[0] == 0, res.status()
+        if args.skip_check:
+            continue
         v0 = np.frombuffer(res.batch(0, 0)["values"], dtype=np.int64)
         assert np.array_equal(v0[:4], st["first"])
         nb = res.n_batches
@@ -186,6 +193,10 @@ def main():
         "mrows_per_s": round(total_rows / (dt / args.steps) / 1e6, 1),
         "stream_bytes_in": stream_bytes, "arrow_bytes_out": arrow_bytes,
         "device_ms_per_step": round(tot_ms / args.steps, 4),
+        # staging the host stream buffers (pinned bounce buffer + hipMemcpyAsync) is outside the timed region;
+        # the PCIe-inclusive rate is reported for DESIGN.md only
+        "h2d_stage_ms": round(t_stage * 1e3, 3),
+        "pcie_inclusive_GBps": round(arrow_bytes / (t_stage + dt / args.steps) / 1e9, 2),
         "roofline": {"bound": "hbm", "kernel": "rle2_expand_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
                      "kernel_ms": round(exp_avg_ms, 4)},
