@@ -273,7 +273,11 @@ static int decode_dense(oo_column* c, uint8_t* dense, size_t k) {
       uint8_t* p = dense;
       /* read through the public reader API: oo_stream pull of `want` bytes */
       extern size_t oo__reader_read(oo_reader*, uint8_t*, size_t);
+      extern int oo__reader_status(const oo_reader*);
       size_t got = oo__reader_read(c->r_data, p, want);
+      /* a block the codec rejects panics in the reference (compression.rs:317,322 unwrap); here it is
+       * reported as Build*Decoder whatever the column type */
+      if (got != want && oo__reader_status(c->r_data) == OO_BUILD_DECODER) return OO_BUILD_DECODER;
       return got == want ? OO_OK : OO_IO_ERROR;
     }
     case OO_T_DECIMAL: {
@@ -465,7 +469,8 @@ int oo_column_next_batch(oo_column* c, uint64_t batch_size, oo_batch* out) {
           acc += vals[i];
           c->offsets[i + 1] = (int32_t)acc;
         }
-        if (got < (size_t)total) st = OO_ARROW; /* try_new: offsets past the values buffer */
+        extern int oo__reader_status(const oo_reader*);
+        if (got < (size_t)total) st = oo__reader_status(c->r_data) == OO_BUILD_DECODER ? OO_BUILD_DECODER : OO_ARROW; /* try_new: offsets past the values buffer */
         if (!st && t != OO_T_BINARY) {
           if (!utf8_valid(c->values, (size_t)total)) st = OO_ARROW;
           for (size_t i = 0; i <= n && !st; i++) {

@@ -685,3 +685,5 @@ void oo_fix_i128_scale(const uint64_t in[2], uint32_t fixed_scale, int32_t varyi
 
 /* internal hook for oo_column.c (Read::read_exact / take().read_to_end on a stream) */
 size_t oo__reader_read(oo_reader* r, uint8_t* buf, size_t n) { return reader_read(r, buf, n); }
+/* sticky reader status (framing IoError / rejected block): raw byte readers report it instead of a plain short read */
+int oo__reader_status(const oo_reader* r) { return r->status; }

@@ -1,0 +1,190 @@
+"""GPU parity, block decompressors on their own: DOUBLE columns carry arbitrary bytes (the DATA
+stream is raw IEEE-754, float.rs:53-75), so every shape of compressed block can be pushed through
+the chunk decoders and compared with the oracle byte for byte.  The blocks come from REAL encoders
+(pyarrow's Snappy / LZ4-raw / Zstandard, Python's zlib) and from a hand-rolled Snappy writer that
+forces the element forms real encoders rarely emit (4-byte offsets, 1..4 extra length bytes,
+overlapping copies of every small distance)."""
+import zlib
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+DOUBLE, DATA = 6, 1
+
+
+def frame(raw, compress, block):
+    """ORC chunk framing (compression.rs:113-123): original chunk when compression does not pay."""
+    parts = []
+    for p in range(0, len(raw), block):
+        blk = raw[p:p + block]
+        comp = compress(blk)
+        if comp is not None and len(comp) < len(blk):
+            h = len(comp) << 1
+            parts.append(bytes([h & 0xFF, (h >> 8) & 0xFF, (h >> 16) & 0xFF]) + comp)
+        else:
+            h = (len(blk) << 1) | 1
+            parts.append(bytes([h & 0xFF, (h >> 8) & 0xFF, (h >> 16) & 0xFF]) + blk)
+    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+
+
+def shapes(seed):
+    rng = np.random.default_rng(seed)
+    rnd = lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    words = [b"AIR", b"FOB", b"MAIL", b"RAIL", b"REG AIR", b"SHIP", b"TRUCK", b"DELIVER IN PERSON", b"NONE", b"TAKE BACK RETURN"]
+    text = b" ".join(words[i] for i in rng.integers(0, len(words), 60000))
+    far = rnd(30000)
+    far2 = rnd(100000)
+    out = {
+        "zeros": bytes(600000),                                             # distance-1 overlapping copies, very long matches
+        "period7": (b"abcdefg" * 90000)[:600000],                           # distance < length
+        "period3": (b"xyz" * 200000)[:600000],
+        "random": rnd(300000),                                              # literal only (original chunks)
+        "random+zeros": rnd(70000) + bytes(50000) + rnd(3000) + bytes(200000),  # long literals inside compressed chunks
+        "text": text,                                                       # short literals and copies, small distances
+        "bitmap": (rng.random(400000) < 0.43).astype(np.uint8).tobytes().replace(b"\x01", b"\xff"),  # token-heavy
+        "far30k": far + rnd(500) + far + rnd(700) + far,                    # distances of ~30 KB (behind a 32 KiB ring's near zone)
+        "far100k": far2 + rnd(100) + far2,                                  # distances of 100 KB (Zstandard windows)
+        "short": b"orc",                                                    # smaller than any header
+    }
+    return {k: v + bytes((-len(v)) % 8) for k, v in out.items()}
+
+
+CODECS = {
+    "snappy": lambda b: pa.Codec("snappy").compress(b, asbytes=True),
+    "lz4": lambda b: pa.Codec("lz4_raw").compress(b, asbytes=True),
+    "zstd": lambda b: pa.Codec("zstd", compression_level=3).compress(b, asbytes=True),
+    "zlib": lambda b: (lambda c: c.compress(b) + c.flush())(zlib.compressobj(6, zlib.DEFLATED, -15)),
+}
+
+
+@pytest.mark.parametrize("kind", ["snappy", "lz4", "zlib", "zstd"])
+@pytest.mark.parametrize("block", [262144, 65536, 1000])
+def test_real_encoders(kind, block):
+    cols, streams, names = [], [], []
+    for name, raw in shapes(block).items():
+        if len(raw) == 0:
+            continue
+        cid = len(cols) + 1
+        cols.append({"column_id": cid, "orc_type": DOUBLE, "encoding": 0})
+        streams.append((cid, DATA, frame(raw, CODECS[kind], block)))
+        names.append((name, len(raw) // 8))
+    # the stripe has as many rows as its shortest column needs; every column is compared over its own length
+    for ci, c in enumerate(cols):
+        n = names[ci][1]
+        res = G.gpu_decode(n, [c], [streams[ci]], compression=kind, block_size=block)
+        assert res.status()[0] == 0, (kind, block, names[ci], res.status())
+        G.assert_column_parity(res, 0, c, [streams[ci]], n, 8192, compression=kind, block_size=block, what=(kind, block, names[ci]))
+        res.free()
+
+
+# ---- hand-rolled Snappy: the element forms encoders rarely produce ---------------------------------
+
+def sn_varint(n):
+    out = bytearray()
+    while n >= 0x80:
+        out.append((n & 0x7F) | 0x80)
+        n >>= 7
+    out.append(n)
+    return bytes(out)
+
+
+def sn_literal(data, force_ext=0):
+    n = len(data) - 1
+    if force_ext == 0 and n < 60:
+        return bytes([n << 2]) + data
+    nb = max(force_ext, 1 if n < 256 else 2 if n < 65536 else 3 if n < (1 << 24) else 4)
+    return bytes([(59 + nb) << 2]) + n.to_bytes(nb, "little") + data
+
+
+def sn_copy(off, ln, form):
+    if form == 1:
+        assert 4 <= ln <= 11 and off < 2048
+        return bytes([1 | ((ln - 4) << 2) | ((off >> 8) << 5), off & 0xFF])
+    if form == 2:
+        assert 1 <= ln <= 64 and off < 65536
+        return bytes([2 | ((ln - 1) << 2)]) + off.to_bytes(2, "little")
+    assert 1 <= ln <= 64
+    return bytes([3 | ((ln - 1) << 2)]) + off.to_bytes(4, "little")
+
+
+def build_snappy(seed, total):
+    """(plain, block): random element soup; every copy is applied to a Python model of the output."""
+    rng = np.random.default_rng(seed)
+    plain = bytearray()
+    body = bytearray()
+    while len(plain) < total:
+        r = rng.random()
+        if r < 0.30 or len(plain) < 16:
+            ln = int(rng.choice([1, 2, 5, 59, 60, 61, 64, 65, 200, 255, 256, 257, 5000, 70000]))
+            data = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+            ext = int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
+            if ext and ln - 1 >= (1 << (8 * ext)):
+                ext = 0
+            body += sn_literal(data, ext)
+            plain += data
+            continue
+        form = int(rng.choice([1, 2, 2, 3]))
+        ln = int(rng.integers(4, 12)) if form == 1 else int(rng.integers(1, 65))
+        maxoff = min(len(plain), 2047 if form == 1 else 65535 if form == 2 else len(plain))
+        pick = rng.random()
+        if pick < 0.35:
+            off = int(rng.integers(1, min(maxoff, 8) + 1))        # overlapping, tiny distances
+        elif pick < 0.7:
+            off = int(rng.integers(1, min(maxoff, 300) + 1))       # inside the current group of elements
+        else:
+            off = int(rng.integers(1, maxoff + 1))                  # anywhere, far ones included (form 3: > 64 KiB)
+        body += sn_copy(off, ln, form)
+        start = len(plain) - off
+        for k in range(ln):
+            plain.append(plain[start + k])
+    plain = bytes(plain)
+    pad = (-len(plain)) % 8
+    if pad:
+        body += sn_literal(bytes(pad))
+        plain += bytes(pad)
+    return plain, sn_varint(len(plain)) + bytes(body)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_handmade_snappy_elements(seed):
+    plain, block = build_snappy(seed, 250000)
+    assert len(block) < (1 << 23)
+    h = len(block) << 1
+    stream = np.frombuffer(bytes([h & 0xFF, (h >> 8) & 0xFF, (h >> 16) & 0xFF]) + block, dtype=np.uint8).copy()
+    n = len(plain) // 8
+    bs = 1 << 19  # the chunk's plain size must fit the declared compression block size
+    assert len(plain) <= bs
+    c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+    res = G.gpu_decode(n, [c], [(1, DATA, stream)], compression="snappy", block_size=bs)
+    assert res.status()[0] == 0, res.status()
+    got = b"".join(bytes(res.batch(b, 0)["values"]) for b in range(res.n_batches))
+    assert got == plain
+    G.assert_column_parity(res, 0, c, [(1, DATA, stream)], n, 8192, compression="snappy", block_size=bs, what=("handmade", seed))
+
+
+@pytest.mark.parametrize("case", ["offset0", "offset_too_far", "literal_overrun", "length_mismatch", "truncated_tag"])
+def test_malformed_snappy_is_rejected_like_the_oracle(case):
+    data = bytes(range(64)) * 8
+    body = sn_literal(data[:40])
+    if case == "offset0":
+        body += sn_copy(0, 8, 2)
+    elif case == "offset_too_far":
+        body += sn_copy(41, 8, 2)
+    elif case == "literal_overrun":
+        body += bytes([(59 + 2) << 2]) + (5000).to_bytes(2, "little") + b"abc"
+    elif case == "length_mismatch":
+        body += sn_literal(data[:24])
+    else:
+        body += bytes([2 | (7 << 2), 5])  # 2-byte-offset copy with one offset byte missing
+    block = sn_varint(512) + body
+    h = len(block) << 1
+    stream = np.frombuffer(bytes([h & 0xFF, (h >> 8) & 0xFF, (h >> 16) & 0xFF]) + block, dtype=np.uint8).copy()
+    c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+    res = G.gpu_decode(64, [c], [(1, DATA, stream)], compression="snappy", block_size=4096)
+    assert res.status()[0] != 0
+    G.assert_column_parity(res, 0, c, [(1, DATA, stream)], 64, 8192, compression="snappy", block_size=4096, what=case)
