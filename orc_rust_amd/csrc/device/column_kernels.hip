@@ -4,6 +4,7 @@
 //   validity is LSB-first, omitted per batch when the batch has no nulls (array_decoder/mod.rs:247-251).
 //   decode_spaced leaves null slots at the caller's zero fill (encoding/mod.rs:64-91).
 //   Timestamp combine: encoding/timestamp.rs:121-192.  Decimal scale repair: array_decoder/decimal.rs:138-166.
+#include "rle_kernels.h"
 #include "rle_parse.h"
 
 struct ErrSlot {
@@ -16,16 +17,26 @@ __device__ __forceinline__ void report_row(unsigned long long* err, uint64_t idx
 
 // ------------------------------------------------------------------------------------------------
 // PRESENT bytes (MSB-first) -> stripe-wide LSB-first bitmap words + per-word popcount.
-// One thread per 64 rows.  `avail_bytes` = scalars[total_idx] of the PRESENT byte-RLE job: rows
-// beyond the decoded bytes are treated as valid (the reference swallows a PRESENT decode error
-// and decodes the batch as if there were no PRESENT stream: derive_present_vec, mod.rs:247-251).
+// One thread per 64 rows.  A PRESENT stream that fails to decode does not fail the column: the
+// reference swallows the error and decodes the batch -- and, its decoder being at the end of its
+// input, every later batch -- as if there were no PRESENT stream (derive_present_vec,
+// array_decoder/mod.rs:228-251, `_ => None`).  job->err holds the number of bytes decoded before
+// the failing run: rows from the first batch those bits do not cover are valid.
 extern "C" __global__ void __launch_bounds__(256) present_words_kernel(const uint8_t* pbytes, uint64_t n_rows, unsigned long long* vbits,
-                                                                        uint32_t* wpop, uint64_t n_words) {
+                                                                        uint32_t* wpop, uint64_t n_words, const RleJob* job, uint32_t batch) {
   uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (w >= n_words) return;
   uint64_t x = ld_u64(pbytes + w * 8);
   // reverse the bits inside each byte: bitreverse64 reverses everything, bswap restores byte order
   unsigned long long v = __builtin_bswap64(__builtin_bitreverse64(x));
+  const unsigned long long e = job->err;
+  if (e != RLE_NO_ERR) {
+    const uint64_t bits = (e >> 8) * 8;
+    if (bits < n_rows) {
+      const uint64_t cutoff = bits / batch * batch;  // first row of the batch that fails
+      if (w * 64 + 64 > cutoff) v |= w * 64 >= cutoff ? ~0ull : ~0ull << (cutoff - w * 64);
+    }
+  }
   uint64_t rows_here = n_rows - w * 64;
   if (rows_here < 64) v &= (1ull << rows_here) - 1;
   vbits[w] = v;

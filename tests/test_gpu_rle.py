@@ -80,6 +80,26 @@ def test_nulls_spacing(null_frac):
             G.assert_column_parity(res, ci, c, streams, n, batch, what=("nulls", null_frac, ci, batch))
 
 
+@pytest.mark.parametrize("cut", [0, 1, 37, 500, 1023, 1024, 1500, 3000])
+def test_present_stream_that_fails_is_swallowed(cut):
+    """derive_present_vec (array_decoder/mod.rs:228-251) maps a PRESENT decode error to "no PRESENT
+    stream": the failing batch and every later one are decoded with all rows valid."""
+    n = 30000
+    rng = np.random.default_rng(cut)
+    present = (rng.random(n) >= 0.3).astype(np.uint8)
+    pstream = gen.boolean(present)
+    pcut = pstream[: min(cut, len(pstream))]
+    # enough DATA values for any outcome (all rows valid from some batch on)
+    vals = rng.integers(-1000, 1000, n)
+    cols = [col(1, LONG), col(2, INT)]
+    streams = [(1, PRESENT, pcut), (1, DATA, gen.rle2(vals, signed=True)), (2, PRESENT, pcut), (2, DATA, gen.rle2(vals % 100, signed=True))]
+    for batch in (8192, 1000):
+        res = G.gpu_decode(n, cols, streams, batch_size=batch)
+        for ci, c in enumerate(cols):
+            G.assert_column_parity(res, ci, c, streams, n, batch, what=("present-cut", cut, ci, batch))
+        res.free()
+
+
 def test_rlev1_columns():
     n = 30000
     rng = np.random.default_rng(11)
