@@ -102,13 +102,14 @@ extern "C" __global__ void __launch_bounds__(256) validity_batches_kernel(const 
                                                                            uint32_t words_per_batch, unsigned long long* out,
                                                                            unsigned long long* null_counts, uint64_t n_out_words) {
   uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n_out_words) return;
+  const bool live = t < n_out_words;
+  if (!live) t = n_out_words - 1;  // stays in the wavefront for the reduction below, contributes nothing
   uint64_t b = t / words_per_batch, w = t % words_per_batch;
   uint64_t row0 = b * batch + w * 64;
   uint64_t bend = (b + 1) * (uint64_t)batch;
   if (bend > n_rows) bend = n_rows;
   unsigned long long v = 0;
-  uint32_t rows = 0;
+  uint32_t rows = 0, nulls = 0;
   if (row0 < bend) {
     rows = bend - row0 < 64 ? (uint32_t)(bend - row0) : 64;
     uint64_t sw = row0 >> 6;
@@ -117,10 +118,17 @@ extern "C" __global__ void __launch_bounds__(256) validity_batches_kernel(const 
     unsigned long long hi = (sh && ((sw + 1) * 64 < n_rows)) ? vbits[sw + 1] : 0;
     v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
     if (rows < 64) v &= (1ull << rows) - 1;
-    uint32_t nulls = rows - (uint32_t)__builtin_popcountll(v);
-    if (nulls) atomicAdd(&null_counts[b], (unsigned long long)nulls);
+    nulls = live ? rows - (uint32_t)__builtin_popcountll(v) : 0;
   }
-  out[t] = v;
+  if (live) out[t] = v;
+  // one atomic per wavefront when its 64 words belong to one batch (the common case), not one per word
+  const uint64_t b0 = __shfl((unsigned long long)b, 0);
+  if (__ballot(b != b0) == 0) {
+    for (int o = 32; o; o >>= 1) nulls += __shfl_xor(nulls, o);
+    if ((threadIdx.x & 63) == 0 && nulls) atomicAdd(&null_counts[b0], (unsigned long long)nulls);
+  } else if (nulls) {
+    atomicAdd(&null_counts[b], (unsigned long long)nulls);
+  }
 }
 
 // Null spacing for fixed-width values: out[i] = valid(i) ? dense[rank(i)] : 0   (encoding/mod.rs:64-91)
@@ -158,7 +166,8 @@ extern "C" __global__ void __launch_bounds__(256) bool_values_kernel(const uint8
                                                                       uint64_t n_rows, uint32_t batch, uint32_t words_per_batch,
                                                                       unsigned long long* out, uint64_t n_out_words) {
   uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n_out_words) return;
+  const bool live = t < n_out_words;
+  if (!live) t = n_out_words - 1;  // stays in the wavefront for the reduction below, contributes nothing
   uint64_t b = t / words_per_batch, w = t % words_per_batch;
   uint64_t row0 = b * batch + w * 64;
   uint64_t bend = (b + 1) * (uint64_t)batch;

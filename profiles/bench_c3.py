@@ -2,7 +2,9 @@
 Snappy, l_shipmode-like 7-entry dictionary, 10 % nulls."""
 import sys, time, json, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in profiles/); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in profiles/)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from orc_rust_amd import capi, gen
 rows = int(os.environ.get("ROWS", 100_000_000)); stripe_rows = 8_388_608
 comp = os.environ.get("COMP", "snappy")
