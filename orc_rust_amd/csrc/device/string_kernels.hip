@@ -136,6 +136,234 @@ extern "C" __global__ void __launch_bounds__(256) dict_gather_kernel(const int32
   for (; k < len; k++) d[k] = src[k];
 }
 
+// ---- dictionary-encoded strings, all columns of a call in one launch ------------------------------------------
+// DictionaryStringArrayDecoder::next_batch (array_decoder/string.rs:204-224) per batch: keys
+// (bounds-checked) -> lengths -> int32 offsets restarting at 0 -> gather of the entries.
+struct DictJob {
+  const int64_t* dense;             // decoded keys of the non-null rows
+  const unsigned long long* vbits;  // stripe-wide validity words (null: no PRESENT stream)
+  const uint32_t* rank;             // non-null rows before each 64-row word
+  const int32_t* doff;              // dictionary offsets (dict_n + 1)
+  const uint8_t* dbytes;            // dictionary bytes
+  int32_t* offsets;                 // out: batch b at b * (batch + 1)
+  int32_t* keys;                    // workspace: key per row (0 for nulls)
+  unsigned long long* chartot;      // per-batch byte totals, then (at + n_batches) their exclusive scan
+  unsigned long long* err;
+  uint8_t* out_chars;               // value bytes of the column (set for the gather launch)
+  uint64_t* total_out;              // scalar receiving the column's total value bytes
+  uint64_t n_rows;
+  uint32_t batch, n_batches;
+  uint32_t dict_n_idx;              // scalar holding the dictionary size
+  uint32_t pad;
+};
+#define DICT_TILE 8192u
+#define DICT_DOFF_LDS 2048u
+
+// One workgroup per (batch, column): keys -> lengths -> offsets.  Rows are read coalesced into an
+// LDS tile (padded: thread t then scans entries 32t..32t+31 without bank conflicts), one block scan
+// of the 256 partial sums, offsets written back coalesced.
+extern "C" __global__ void __launch_bounds__(256) dict_rows_kernel(const DictJob* jobs, const uint64_t* scalars) {
+  __shared__ uint32_t lens[DICT_TILE + DICT_TILE / 32];
+  __shared__ int32_t doffc[DICT_DOFF_LDS + 1];
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t tbase[256];
+  const DictJob j = jobs[blockIdx.y];
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  if (b >= j.n_batches) return;
+  const uint64_t dict_n = scalars[j.dict_n_idx];
+  const bool cached = dict_n <= DICT_DOFF_LDS;
+  if (cached)
+    for (uint32_t i = tid; i <= dict_n; i += 256) doffc[i] = j.doff[i];
+  __syncthreads();
+  const uint64_t row0 = (uint64_t)b * j.batch;
+  const uint64_t rows = j.n_rows - row0 < j.batch ? j.n_rows - row0 : j.batch;
+  int32_t* out = j.offsets + (uint64_t)b * ((uint64_t)j.batch + 1);
+  uint64_t carry = 0;
+  for (uint64_t t0 = 0; t0 < rows; t0 += DICT_TILE) {
+    const uint32_t tn = rows - t0 < DICT_TILE ? (uint32_t)(rows - t0) : DICT_TILE;
+    // 1. keys and lengths of the tile: eight rows per trip, the loads of all eight issued together
+    //    (validity word + rank, then the key) -- the chain of dependent loads is what this step costs
+    for (uint32_t k0 = tid; k0 < DICT_TILE; k0 += 256 * 8) {
+      unsigned long long word[8];
+      uint32_t rk[8];
+      int64_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t k = k0 + u * 256;
+        const uint64_t i = row0 + t0 + (k < tn ? k : 0);
+        word[u] = j.vbits ? j.vbits[i >> 6] : ~0ull;
+        rk[u] = j.vbits ? j.rank[i >> 6] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t k = k0 + u * 256;
+        const uint64_t i = row0 + t0 + (k < tn ? k : 0);
+        const uint32_t bit = i & 63;
+        const bool valid = k < tn && ((word[u] >> bit) & 1);
+        const uint64_t di = j.vbits ? (uint64_t)rk[u] + __builtin_popcountll(word[u] & ((1ull << bit) - 1)) : i;
+        v[u] = j.dense[valid ? di : 0];
+        if (!valid) v[u] = -1;  // null row (or behind the tile): no key
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t k = k0 + u * 256;
+        const uint64_t i = row0 + t0 + k;
+        const bool valid = k < tn && ((word[u] >> (i & 63)) & 1);
+        uint32_t len = 0;
+        int32_t key = 0;
+        if (valid) {
+          if (v[u] < 0 || (uint64_t)v[u] >= dict_n) {
+            report_err64(j.err, i, ORC_E_ARROW);
+          } else {
+            key = (int32_t)v[u];
+            len = cached ? (uint32_t)(doffc[v[u] + 1] - doffc[v[u]]) : (uint32_t)(j.doff[v[u] + 1] - j.doff[v[u]]);
+          }
+        }
+        if (k < tn) j.keys[i] = key;
+        lens[k + (k >> 5)] = len;
+      }
+    }
+    __syncthreads();
+    // 2. thread-local exclusive scan of 32 consecutive entries
+    uint64_t run = 0;
+    {
+      const uint32_t base = tid * 33;
+      for (uint32_t m = 0; m < 32; m++) {
+        const uint32_t l = lens[base + m];
+        lens[base + m] = (uint32_t)run;  // < 2^32: checked against i32::MAX per batch below
+        run += l;
+      }
+    }
+    // 3. block scan of the 256 sums
+    uint64_t incl = run;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint64_t t = __shfl_up(incl, o);
+      if ((int)(tid & 63) >= o) incl += t;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint64_t wbase = carry;
+    for (uint32_t w = 0; w < (tid >> 6); w++) wbase += wsum[w];
+    tbase[tid] = wbase + incl - run;
+    const uint64_t tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    // 4. offsets, coalesced
+    for (uint32_t k = tid; k < tn; k += 256) out[t0 + k] = (int32_t)(tbase[k >> 5] + lens[k + (k >> 5)]);
+    carry += tile_total;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    out[rows] = (int32_t)carry;
+    j.chartot[b] = carry;
+    if (carry > 0x7fffffffull) report_err64(j.err, row0, ORC_E_ARROW);
+  }
+}
+
+// One workgroup per column: exclusive scan of the per-batch totals -> chartot[n_batches + b]; grand total.
+extern "C" __global__ void __launch_bounds__(256) dict_base_kernel(const DictJob* jobs) {
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t carry_s;
+  const DictJob j = jobs[blockIdx.x];
+  unsigned long long* charbase = j.chartot + j.n_batches;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t s = 0; s < j.n_batches; s += 256) {
+    uint32_t i = s + threadIdx.x;
+    uint64_t v = i < j.n_batches ? j.chartot[i] : 0;
+    uint64_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint64_t t = __shfl_up(incl, o);
+      if ((int)(threadIdx.x & 63) >= o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t wbase = carry_s;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += wsum[w];
+    if (i < j.n_batches) charbase[i] = wbase + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = wbase + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *j.total_out = carry_s;
+}
+
+// One workgroup per (batch, column): the batch's value bytes are assembled in LDS (every thread
+// copies the entries of its rows to their offsets) and written to HBM as one coalesced run; batches
+// whose bytes do not fit go row by row straight to memory.
+#define DICT_CHARS_LDS 49152u
+#define DICT_BYTES_LDS 8192u
+extern "C" __global__ void __launch_bounds__(256) dict_gather2_kernel(const DictJob* jobs, const uint64_t* scalars) {
+  __shared__ __attribute__((aligned(16))) uint8_t chars[DICT_CHARS_LDS + 16];
+  __shared__ int32_t doffc[DICT_DOFF_LDS + 1];
+  __shared__ uint8_t dbc[DICT_BYTES_LDS];
+  const DictJob j = jobs[blockIdx.y];
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  if (b >= j.n_batches) return;
+  const uint64_t total = j.chartot[b];
+  if (!total || !j.out_chars) return;
+  const uint64_t row0 = (uint64_t)b * j.batch;
+  const uint32_t rows = (uint32_t)(j.n_rows - row0 < j.batch ? j.n_rows - row0 : j.batch);
+  const int32_t* off = j.offsets + (uint64_t)b * ((uint64_t)j.batch + 1);
+  uint8_t* out = j.out_chars + j.chartot[j.n_batches + b];
+  const bool staged = total <= DICT_CHARS_LDS;
+  // small dictionaries are copied to LDS once per workgroup (offsets and bytes)
+  const uint64_t dict_n = scalars[j.dict_n_idx];
+  const uint32_t dict_bytes = dict_n <= DICT_DOFF_LDS ? (uint32_t)j.doff[dict_n] : 0xffffffffu;
+  const bool dcached = staged && dict_n <= DICT_DOFF_LDS && dict_bytes <= DICT_BYTES_LDS;
+  if (dcached) {
+    for (uint32_t i = tid; i <= dict_n; i += 256) doffc[i] = j.doff[i];
+    for (uint32_t i = tid; i < dict_bytes; i += 256) dbc[i] = j.dbytes[i];
+    __syncthreads();
+  }
+  for (uint32_t k0 = tid; k0 < rows; k0 += 256 * 4) {
+    // four rows per trip: offsets and keys of all four are requested before any is used
+    uint32_t o[4], e[4];
+    int32_t key[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t k = k0 + u * 256 < rows ? k0 + u * 256 : k0;
+      o[u] = (uint32_t)off[k];
+      e[u] = (uint32_t)off[k + 1];
+      key[u] = j.keys[row0 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k0 + u * 256 >= rows) continue;
+      const uint32_t len = e[u] - o[u];
+      if (!len) continue;
+      uint8_t* d = staged ? chars + o[u] : out + o[u];
+      if (dcached) {
+        const uint8_t* src = dbc + doffc[key[u]];
+        for (uint32_t m = 0; m < len; m++) d[m] = src[m];
+      } else {
+        const uint8_t* src = j.dbytes + j.doff[key[u]];
+        uint32_t m = 0;
+        if (!staged)
+          for (; m + 8 <= len; m += 8) {
+            uint64_t v = ld_u64(src + m);
+            __builtin_memcpy(d + m, &v, 8);
+          }
+        for (; m < len; m++) d[m] = src[m];
+      }
+    }
+  }
+  if (!staged) return;
+  __syncthreads();
+  // LDS -> HBM: bytes up to the first 16-byte boundary of the destination one by one, then 16 at a time
+  const uint32_t n = (uint32_t)total;
+  uint32_t head = (uint32_t)((16 - ((uintptr_t)out & 15)) & 15);
+  if (head > n) head = n;
+  if (tid < head) out[tid] = chars[tid];
+  const uint32_t body = (n - head) / 16;
+  for (uint32_t q = tid; q < body; q += 256) {
+    uint64_t v[2];
+    __builtin_memcpy(v, chars + head + q * 16, 16);
+    __builtin_memcpy(out + head + (uint64_t)q * 16, v, 16);
+  }
+  const uint32_t done = head + body * 16;
+  if (tid < n - done) out[done + tid] = chars[done + tid];
+}
+
 // ---- dictionary lengths -> dictionary offsets (single workgroup; the dictionary is loaded once per stripe)
 extern "C" __global__ void __launch_bounds__(256) dict_offsets_kernel(const int64_t* dlens, const uint64_t* scalars, uint32_t dict_n_idx,
                                                                        uint32_t data_len_idx, int32_t* dict_off, uint64_t* dict_bytes_out,
