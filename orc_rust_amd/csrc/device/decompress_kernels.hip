@@ -464,47 +464,169 @@ __device__ __forceinline__ int snappy_wave(const uint8_t* src, uint32_t n, uint8
 }
 
 // ---- LZ4 block (compression.rs:185-195) ------------------------------------------------------------------
-__device__ __forceinline__ int lz4_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t lane, uint32_t* out_len, LzLds Z) {
+// Same scheme as Snappy: every lane decodes the SEQUENCE (token, literal length, literals, offset,
+// match length) that would start at its byte, the chain is followed with cross-lane reads, literal
+// and match parts are filed as group elements.  Sequences with more than two length-extension bytes,
+// literals or matches longer than 64 bytes take the one-at-a-time path.
+__device__ __forceinline__ int lz4_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t lane, uint32_t* out_len, LzLds Z PROF_PARM) {
   if (n == 0) return 1;
   LzIn in{src, n, Z.stage, 0};
   lzin_stage(in, 0, lane);
   LzOut o{Z.ring, Z.rsize - 1, dst, 0, 0};
+  LzGroup G{0, 0, 0, 0};
+  uint32_t gn = 0;  // elements in the group table (wave uniform)
+  auto run_group = [&]() -> int {
+    lds_order();
+    G.len = lane < gn ? Z.g_len[lane] : 0;
+    G.off = lane < gn ? Z.g_off[lane] : 0;
+    G.src = lane < gn ? Z.g_src[lane] : 0;
+    G.n = gn;
+    gn = 0;
+    return lz_group_run(G, in, o, cap, lane PROF_ARG);
+  };
   uint32_t pos = 0;
-  for (;;) {
-    if (pos >= n) return 1;
-    const uint32_t tok = (uint32_t)lzin_peek(in, pos, lane) & 0xff;
-    pos++;
-    uint32_t lit = tok >> 4;
-    if (lit == 15) {
-      uint32_t c;
-      do {
-        if (pos >= n) return 1;
-        c = (uint32_t)lzin_peek(in, pos, lane) & 0xff;
-        pos++;
-        lit += c;
-      } while (c == 255);
+  bool done = false;
+  while (!done) {
+    if (pos >= n) return 1;  // a block ends with a literals-only sequence, never between sequences
+    if (gn > 20 && run_group()) return 1;  // a 64-byte window holds at most 21 sequences = 42 elements
+    // the stage must hold a short sequence starting anywhere in the window: 64 + token/extensions + 525 literal bytes + offset/extensions
+    if (pos < in.sb || pos + 640 > in.sb + LZ_STAGE + 16) lzin_stage(in, pos, lane);
+    const uint32_t q = pos + lane;
+    uint32_t flag = 0, adv = 0, ll = 0, ml = 0, off = 0, lsrc = 0;
+    if (q >= n) {
+      flag = 4;
+    } else {
+      uint64_t w;
+      __builtin_memcpy(&w, in.stage + (q - in.sb), 8);
+      const uint32_t tok = (uint32_t)w & 0xff;
+      ll = tok >> 4;
+      uint32_t p = 1;  // bytes of the sequence consumed so far
+      if (ll == 15) {
+        const uint32_t e0 = (uint32_t)(w >> 8) & 0xff, e1 = (uint32_t)(w >> 16) & 0xff;
+        ll += e0;
+        p = 2;
+        if (e0 == 255) {
+          ll += e1;
+          p = 3;
+          if (e1 == 255) flag = 2;  // longer extension: one-at-a-time path
+        }
+      }
+      lsrc = q + p;
+      const uint64_t lit_end = (uint64_t)lsrc + ll;
+      if (ll > 525) flag = 2;
+      if (!flag) {
+        if (lit_end > n) {
+          flag = 1;
+        } else if (lit_end == n) {
+          flag = 8;  // last sequence: literals only
+          adv = (uint32_t)(lit_end - q);
+        } else if (lit_end + 2 > n) {
+          flag = 1;
+        } else {
+          uint64_t w2;
+          __builtin_memcpy(&w2, in.stage + ((uint32_t)lit_end - in.sb), 8);
+          off = (uint32_t)w2 & 0xffff;
+          ml = tok & 15;
+          uint32_t p2 = 2;
+          if (ml == 15) {
+            const uint32_t e0 = (uint32_t)(w2 >> 16) & 0xff, e1 = (uint32_t)(w2 >> 24) & 0xff;
+            ml += e0;
+            p2 = 3;
+            if (e0 == 255) {
+              ml += e1;
+              p2 = 4;
+              if (e1 == 255) flag = 2;
+            }
+          }
+          ml += 4;
+          if (lit_end + p2 > n) flag = 1;  // extension bytes behind the end
+          if (!flag && off == 0) flag = 1;
+          adv = (uint32_t)(lit_end - q) + p2;
+        }
+      }
+      if (!flag && (ll > 64 || ml > 64)) flag = 16;  // well-formed, but its parts are too long for a group element
     }
-    if ((uint64_t)pos + lit > n || o.out + lit > cap) return 1;
-    lzin_literal(in, o, pos, lit, lane);
-    pos += lit;
-    if (pos == n) break;
-    if (pos + 2 > n) return 1;
-    const uint32_t off = (uint32_t)lzin_peek(in, pos, lane) & 0xffff;
-    pos += 2;
-    uint32_t ml = tok & 15;
-    if (ml == 15) {
-      uint32_t c;
-      do {
-        if (pos >= n) return 1;
-        c = (uint32_t)lzin_peek(in, pos, lane) & 0xff;
-        pos++;
-        ml += c;
-      } while (c == 255);
+    const uint32_t hop = (flag & ~8u) ? (flag << 16) : adv;  // the last sequence (8) is a member; its hop ends the input
+    // ---- follow the chain from lane 0 ----
+    unsigned long long members = 0;
+    uint32_t cur = 0, stop = 0;
+    {
+      uint32_t last = 0, h = 0;
+      while (cur < 64) {
+        h = (uint32_t)__builtin_amdgcn_readlane((int)hop, (int)cur);
+        members |= 1ull << cur;
+        last = cur;
+        cur += h;
+      }
+      if (h >> 16) {
+        stop = h >> 16;
+        members &= ~(1ull << last);
+        cur = last;
+      }
     }
-    ml += 4;
-    if (off == 0 || off > o.out || o.out + ml > cap) return 1;
-    lz_match(o, off, ml, lane);
+    // ---- members -> group table: literal part, then match part ----
+    const bool mem = (members >> lane) & 1;
+    const bool is_last = mem && (flag & 8);
+    const uint32_t cnt = mem ? (ll ? 1u : 0u) + (is_last ? 0u : 1u) : 0u;
+    const uint32_t incl = wave_incl_scan_u32(cnt, lane);
+    if (mem) {
+      uint32_t slot = gn + incl - cnt;
+      if (ll) {
+        Z.g_len[slot] = ll;
+        Z.g_off[slot] = 0;
+        Z.g_src[slot] = lsrc;
+        slot++;
+      }
+      if (!is_last) {
+        Z.g_len[slot] = ml;
+        Z.g_off[slot] = off;
+        Z.g_src[slot] = 0;
+      }
+    }
+    gn += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (__ballot(is_last)) done = true;
+    pos += cur;
+    if (stop & 1) return 1;
+    if (stop & (2 | 16)) {
+      // one sequence the slow way (all lanes on it): everything filed so far first
+      if (run_group()) return 1;
+      const uint32_t tok = src[pos];
+      pos++;
+      uint32_t lit = tok >> 4;
+      if (lit == 15) {
+        uint32_t c;
+        do {
+          if (pos >= n) return 1;
+          c = src[pos++];
+          lit += c;
+        } while (c == 255);
+      }
+      if ((uint64_t)pos + lit > n || o.out + lit > cap) return 1;
+      lz_literal(o, src + pos, lit, lane);
+      pos += lit;
+      if (pos == n) {
+        done = true;
+      } else {
+        if (pos + 2 > n) return 1;
+        const uint32_t moff = src[pos] | ((uint32_t)src[pos + 1] << 8);
+        pos += 2;
+        uint32_t mlen = tok & 15;
+        if (mlen == 15) {
+          uint32_t c;
+          do {
+            if (pos >= n) return 1;
+            c = src[pos++];
+            mlen += c;
+          } while (c == 255);
+        }
+        mlen += 4;
+        if (moff == 0 || moff > o.out || o.out + mlen > cap) return 1;
+        lz_match(o, moff, mlen, lane);
+      }
+    }
   }
+  if (run_group()) return 1;
+  if (pos != n) return 1;
   lz_flush(o, lane);
   *out_len = (uint32_t)o.out;
   return 0;
@@ -541,7 +663,7 @@ __device__ __forceinline__ void decompress_chunks_body(ChunkDesc* chunks, uint32
   } else if (FAMILY == 0 && d.kind == 2) {
     bad = snappy_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, lz PROF_ARG);
   } else if (FAMILY == 0 && d.kind == 4) {
-    bad = lz4_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, lz);
+    bad = lz4_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, lz PROF_ARG);
   } else if (FAMILY == 1 && d.kind == 1) {
     bad = inflate_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, *tables, lz);
   } else if (FAMILY == 2 && d.kind == 5) {
