@@ -36,10 +36,14 @@ struct BitRd {
   uint32_t n, pos;
   uint64_t bb;
   uint32_t bc;
+  LzIn* in;  // compressed bytes staged in LDS (refills cost an LDS access, not a memory round trip)
 };
 __device__ __forceinline__ void br_refill(BitRd& b) {
-  // bytes past the end are garbage; overrun is detected at block boundaries via br_overrun()
-  b.bb |= ld_u64(b.src + b.pos) << b.bc;
+  // bytes past the end read as zero; overrun is detected at block boundaries via br_overrun()
+  if (b.pos < b.in->sb || b.pos + 8 > b.in->sb + LZ_STAGE + 16) lzin_stage(*b.in, b.pos, threadIdx.x & 63);
+  uint64_t v;
+  __builtin_memcpy(&v, b.in->stage + (b.pos - b.in->sb), 8);
+  b.bb |= v << b.bc;
   uint32_t adv = (63 - b.bc) >> 3;
   b.pos += adv;
   b.bc += adv * 8;
@@ -162,7 +166,9 @@ __device__ __forceinline__ int inflate_codes_dev(BitRd& b, LzOut& o, uint32_t ca
 
 __device__ __forceinline__ int inflate_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint32_t lane, uint32_t* out_len,
                                              DecompLds& L, LzLds Z) {
-  BitRd b{src, n, 0, 0, 0};
+  LzIn in{src, n, Z.stage, 0};
+  lzin_stage(in, 0, lane);
+  BitRd b{src, n, 0, 0, 0, &in};
   LzOut o{Z.ring, Z.rsize - 1, dst, 0, 0};
   uint32_t last;
   do {
