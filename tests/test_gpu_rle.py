@@ -220,6 +220,84 @@ def test_fixed_delta_full_runs(where, step):
         res.free()
 
 
+@pytest.mark.parametrize("enc", ["rle2", "rle1", "byte", "bool"])
+def test_truncation_sweep(enc):
+    """Every way a stream can end early: the reference yields the complete batches and fails the one
+    that runs dry (IoError / OutOfSpec by sub-encoding).  Sixty cut points per pattern, two batch sizes."""
+    n = 2500
+    rng = np.random.default_rng(7)
+    pats = {name: np.asarray(v, dtype=np.int64) for name, v in patterns(rng, n)}
+    cases = []
+    if enc == "rle2":
+        for name in list(pats)[:6]:
+            cases.append((LONG, 2, gen.rle2(pats[name], signed=True)))
+    elif enc == "rle1":
+        for name in list(pats)[:4]:
+            cases.append((LONG, 0, gen.rle1(pats[name], signed=True)))
+    elif enc == "byte":
+        b = np.repeat(rng.integers(-128, 128, n, dtype=np.int64), rng.integers(1, 6, n))[:n].astype(np.int8)
+        cases.append((BYTE, 0, gen.byte_rle(b)))
+    else:
+        cases.append((BOOLEAN, 0, gen.boolean((rng.random(n) < 0.3).astype(np.uint8))))
+    for typ, e, full in cases:
+        cuts = sorted(set([0, 1, 2, 3, len(full) - 1] + [int(x) for x in rng.integers(0, len(full), 55)]))
+        for cut in cuts:
+            data = full[:cut]
+            c = col(1, typ, enc=e)
+            streams = [(1, DATA, data)]
+            for batch in (1024, 700):
+                res = G.gpu_decode(n, [c], streams, batch_size=batch)
+                G.assert_column_parity(res, 0, c, streams, n, batch, what=(enc, typ, cut, len(full), batch))
+                res.free()
+
+
+@pytest.mark.parametrize("what", ["long+nulls", "boolean+nulls", "string-direct", "string-dict", "decimal", "timestamp"])
+def test_truncation_sweep_columns_with_several_streams(what):
+    """One stream of a multi-stream column cut short at a time (nulls present): the failing batch and the
+    error kind must be the reference's (IoError / OutOfSpec / Arrow / construction-time failures)."""
+    STRING, LENGTH, DICT, DECIMAL = 7, 2, 3, 14
+    n = 2600
+    rng = np.random.default_rng(len(what))
+    present = (rng.random(n) >= 0.2).astype(np.uint8)
+    k = int(present.sum())
+    P = gen.boolean(present)
+    if what == "long+nulls":
+        c = col(1, LONG)
+        streams = {PRESENT: P, DATA: gen.rle2(rng.integers(-10**6, 10**6, k), signed=True)}
+    elif what == "boolean+nulls":
+        c = col(1, BOOLEAN, enc=0)
+        streams = {PRESENT: P, DATA: gen.boolean((rng.random(k) < 0.4).astype(np.uint8))}
+    elif what == "string-direct":
+        words = [b"AIR", b"FOB", b"MAIL", b"RAIL", b"REG AIR", b"", "h\u00e9llo".encode()]
+        idx = rng.integers(0, len(words), k)
+        c = col(1, STRING)
+        streams = {PRESENT: P, LENGTH: gen.rle2(np.array([len(words[i]) for i in idx], dtype=np.int64), signed=False),
+                   DATA: np.frombuffer(b"".join(words[i] for i in idx), dtype=np.uint8)}
+    elif what == "string-dict":
+        dwords = [b"AIR", b"FOB", b"MAIL", b"RAIL", b"REG AIR", b"SHIP", b"TRUCK"]
+        c = col(1, STRING, enc=3, dictionary_size=len(dwords))
+        streams = {PRESENT: P, DATA: gen.rle2(rng.integers(0, len(dwords), k), signed=False),
+                   LENGTH: gen.rle2(np.array([len(w) for w in dwords], dtype=np.int64), signed=False),
+                   DICT: np.frombuffer(b"".join(dwords), dtype=np.uint8)}
+    elif what == "decimal":
+        c = col(1, DECIMAL, precision=38, scale=3)
+        streams = {PRESENT: P, DATA: gen.varint128([int(x) for x in rng.integers(-10**15, 10**15, k)]),
+                   SECONDARY: gen.rle2(rng.integers(0, 6, k), signed=True)}
+    else:
+        secs = rng.integers(-2_000_000_000, 2_000_000_000, k)
+        nanos = rng.integers(0, 1_000_000, k) * 1000
+        c = col(1, TIMESTAMP)
+        streams = {PRESENT: P, DATA: gen.rle2(secs, signed=True), SECONDARY: gen.rle2(np.where(nanos == 0, 0, (nanos // 1000 << 3) | 2), signed=False)}
+    for kind, full in streams.items():
+        cuts = sorted(set([0, 1, max(0, len(full) - 1)] + [int(x) for x in rng.integers(0, max(1, len(full)), 14)]))
+        for cut in cuts:
+            s = [(1, kk, (vv[:cut] if kk == kind else vv)) for kk, vv in streams.items()]
+            for batch in (1024, 700):
+                res = G.gpu_decode(n, [c], s, batch_size=batch)
+                G.assert_column_parity(res, 0, c, s, n, batch, what=(what, "stream", kind, "cut", cut, len(full), batch))
+                res.free()
+
+
 def test_strings_direct_and_dictionary():
     STRING, BINARY, LENGTH, DICT = 7, 8, 2, 3
     n = 30000
