@@ -246,13 +246,16 @@ __device__ __forceinline__ void rle2_parse(const uint8_t* p, uint64_t avail, boo
       h.payload = 4 + bw;
       h.patch_off = h.payload + ((h.n * w + 7) >> 3);
       h.size = h.patch_off + ((h.pl * h.cw + 7) >> 3);
+      // in the order the reference meets them: header, base bytes, first value, payload, patch list
       if (h.pw + h.pgw > 64) {                                           // patched_base.rs:61-67 (after 4 header bytes)
         h.err = ORC_E_OUT_OF_SPEC;
         h.size = 4;
-      } else if (h.size > avail) {
-        h.err = ORC_E_IO;
+      } else if (4 + (uint64_t)bw > avail) {
+        h.err = ORC_E_IO;                                                // i64::read_big_endian(base_byte_width)
       } else if ((w & 7) == 0 && w > (uint32_t)nbits) {
         h.err = ORC_E_OUT_OF_SPEC;                                       // read_big_endian::<N> with too many bytes (panics in the reference)
+      } else if (h.size > avail) {
+        h.err = ORC_E_IO;
       } else if (h.pl == 0) {
         h.err = ORC_E_OUT_OF_SPEC;                                       // patches[0] (index panic in the reference)
       }

@@ -298,6 +298,34 @@ def test_truncation_sweep_columns_with_several_streams(what):
                 res.free()
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13])
+@pytest.mark.parametrize("enc,typ", [("rle2", LONG), ("rle2", INT), ("rle2", SHORT), ("rle1", LONG), ("rle1", INT), ("rle1", SHORT)])
+def test_corruption_sweep(enc, typ, seed):
+    """One byte of a valid stream replaced by a random value, 40 positions per pattern: whatever the
+    damage makes of the stream (other values, OutOfSpec, VarintTooLarge, IoError at the end), batches,
+    values and the failing batch / error kind must be the reference's."""
+    n = 2500
+    rng = np.random.default_rng(seed)
+    bits = {LONG: 40, INT: 31, SHORT: 15}[typ]
+    lim = 1 << (bits - 1)
+    pats = [rng.integers(-lim, lim, n), np.arange(n) % lim, np.repeat(rng.integers(-lim, lim, n // 5 + 1), 5)[:n],
+            np.clip(np.cumsum(rng.integers(0, 200, n)), -lim, lim - 1)]
+    outl = rng.integers(0, 100, n)
+    outl[rng.choice(n, n // 30, replace=False)] = lim - 1
+    pats.append(outl)
+    for v in pats:
+        v = np.asarray(v, dtype=np.int64)
+        full = gen.rle2(v, signed=True) if enc == "rle2" else gen.rle1(v, signed=True)
+        for pos in sorted(set(int(x) for x in rng.integers(0, len(full), 60))):
+            data = full.copy()
+            data[pos] = int(rng.integers(0, 256))
+            c = col(1, typ, enc=2 if enc == "rle2" else 0)
+            streams = [(1, DATA, data)]
+            res = G.gpu_decode(n, [c], streams, batch_size=1024)
+            G.assert_column_parity(res, 0, c, streams, n, 1024, what=(enc, typ, "byte", pos, int(data[pos]), "was", int(full[pos])))
+            res.free()
+
+
 def test_strings_direct_and_dictionary():
     STRING, BINARY, LENGTH, DICT = 7, 8, 2, 3
     n = 30000
