@@ -16,31 +16,109 @@ __device__ __forceinline__ void report_row(unsigned long long* err, uint64_t idx
 }
 
 // ------------------------------------------------------------------------------------------------
-// PRESENT bytes (MSB-first) -> stripe-wide LSB-first bitmap words + per-word popcount.
-// One thread per 64 rows.  A PRESENT stream that fails to decode does not fail the column: the
-// reference swallows the error and decodes the batch -- and, its decoder being at the end of its
-// input, every later batch -- as if there were no PRESENT stream (derive_present_vec,
-// array_decoder/mod.rs:228-251, `_ => None`).  job->err holds the number of bytes decoded before
-// the failing run: rows from the first batch those bits do not cover are valid.
-extern "C" __global__ void __launch_bounds__(256) present_words_kernel(const uint8_t* pbytes, uint64_t n_rows, unsigned long long* vbits,
-                                                                        uint32_t* wpop, uint64_t n_words, const RleJob* job, uint32_t batch) {
-  uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (w >= n_words) return;
-  uint64_t x = ld_u64(pbytes + w * 8);
+// ---- PRESENT streams of ALL columns of a call, one launch per step ----------------------------------------
+// (hundreds of columns x stripes per call: per-column launches of these tiny kernels would cost more
+// than the work; blockIdx.y selects the column, blockIdx.x the piece of it)
+struct PresJob {
+  const uint8_t* pbytes;           // decoded PRESENT bytes (MSB first)
+  unsigned long long* vbits;       // stripe-wide validity words (LSB first)
+  uint32_t* wpop;                  // popcount per word
+  uint32_t* rank;                  // exclusive scan of wpop: non-null rows before each word
+  uint32_t* rtiles;                // per 1024-word tile sums
+  unsigned long long* validity;    // per-batch bitmaps in the result
+  unsigned long long* null_counts; // per batch
+  uint64_t* nonnull_out;           // scalar: non-null rows of the column
+  uint64_t* ceil8_out;             // BOOLEAN columns: ceil(nonnull / 8) (bytes of the DATA job), else null
+  const RleJob* job;               // the PRESENT byte-RLE job (its error word says where decoding stopped)
+  uint64_t n_rows, n_words, n_rank_tiles, n_out_words;
+  uint32_t batch, words_per_batch;
+};
+
+__device__ __forceinline__ void present_word(const PresJob& j, uint64_t w) {
+  uint64_t x = ld_u64(j.pbytes + w * 8);
   // reverse the bits inside each byte: bitreverse64 reverses everything, bswap restores byte order
   unsigned long long v = __builtin_bswap64(__builtin_bitreverse64(x));
-  const unsigned long long e = job->err;
+  const unsigned long long e = j.job->err;
   if (e != RLE_NO_ERR) {
     const uint64_t bits = (e >> 8) * 8;
-    if (bits < n_rows) {
-      const uint64_t cutoff = bits / batch * batch;  // first row of the batch that fails
+    if (bits < j.n_rows) {
+      const uint64_t cutoff = bits / j.batch * j.batch;  // first row of the batch that fails
       if (w * 64 + 64 > cutoff) v |= w * 64 >= cutoff ? ~0ull : ~0ull << (cutoff - w * 64);
     }
   }
-  uint64_t rows_here = n_rows - w * 64;
+  uint64_t rows_here = j.n_rows - w * 64;
   if (rows_here < 64) v &= (1ull << rows_here) - 1;
-  vbits[w] = v;
-  wpop[w] = (uint32_t)__builtin_popcountll(v);
+  j.vbits[w] = v;
+  j.wpop[w] = (uint32_t)__builtin_popcountll(v);
+}
+// PRESENT bytes -> validity words + popcounts.  A PRESENT stream that fails to decode does not fail the
+// column: the reference swallows the error and decodes the batch -- and, its decoder being at the end
+// of its input, every later batch -- as if there were no PRESENT stream (derive_present_vec,
+// array_decoder/mod.rs:228-251, `_ => None`).  job->err holds the number of bytes decoded before the
+// failing run: rows from the first batch those bits do not cover are valid.
+extern "C" __global__ void __launch_bounds__(256) pres_words_kernel(const PresJob* jobs) {
+  const PresJob j = jobs[blockIdx.y];
+  uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w < j.n_words) present_word(j, w);
+}
+extern "C" __global__ void __launch_bounds__(256) pres_scan_tiles_kernel(const PresJob* jobs) {
+  __shared__ uint32_t wsum[4];
+  const PresJob j = jobs[blockIdx.y];
+  if (blockIdx.x >= j.n_rank_tiles) return;
+  const uint64_t n = j.n_words;
+  uint64_t base = (uint64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+  uint32_t v[4];
+  for (int k = 0; k < 4; k++) v[k] = base + k < n ? j.wpop[base + k] : 0;
+  uint32_t s = v[0] + v[1] + v[2] + v[3];
+  uint32_t incl = s;
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(incl, o);
+    if ((int)(threadIdx.x & 63) >= o) incl += t;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += wsum[w];
+  uint32_t e = wbase + incl - s;
+  for (int k = 0; k < 4; k++) {
+    if (base + k < n) j.rank[base + k] = e;
+    e += v[k];
+  }
+  if (threadIdx.x == 255) j.rtiles[blockIdx.x] = e;
+}
+// one workgroup per column: exclusive scan of the tile sums in place, non-null total
+extern "C" __global__ void __launch_bounds__(256) pres_scan_sums_kernel(const PresJob* jobs) {
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t carry_s;
+  const PresJob j = jobs[blockIdx.x];
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint64_t s = 0; s < j.n_rank_tiles; s += 256) {
+    uint64_t i = s + threadIdx.x;
+    uint64_t v = i < j.n_rank_tiles ? j.rtiles[i] : 0;
+    uint64_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint64_t t = __shfl_up(incl, o);
+      if ((int)(threadIdx.x & 63) >= o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t wbase = carry_s;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += wsum[w];
+    if (i < j.n_rank_tiles) j.rtiles[i] = (uint32_t)(wbase + incl - v);
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = wbase + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *j.nonnull_out = carry_s;
+    if (j.ceil8_out) *j.ceil8_out = (carry_s + 7) / 8;
+  }
+}
+extern "C" __global__ void __launch_bounds__(256) pres_scan_apply_kernel(const PresJob* jobs) {
+  const PresJob j = jobs[blockIdx.y];
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < j.n_words) j.rank[i] += j.rtiles[i >> 10];
 }
 
 // Generic 2-level exclusive scan of u32 counts (tile = 1024 entries / workgroup).
@@ -128,6 +206,39 @@ extern "C" __global__ void __launch_bounds__(256) validity_batches_kernel(const 
     if ((threadIdx.x & 63) == 0 && nulls) atomicAdd(&null_counts[b0], (unsigned long long)nulls);
   } else if (nulls) {
     atomicAdd(&null_counts[b], (unsigned long long)nulls);
+  }
+}
+
+// the same for all columns of a call (blockIdx.y = column)
+extern "C" __global__ void __launch_bounds__(256) pres_validity_kernel(const PresJob* jobs) {
+  const PresJob j = jobs[blockIdx.y];
+  if ((uint64_t)blockIdx.x * 256 >= j.n_out_words) return;
+  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = t < j.n_out_words;
+  if (!live) t = j.n_out_words - 1;  // stays in the wavefront for the reduction below, contributes nothing
+  uint64_t b = t / j.words_per_batch, w = t % j.words_per_batch;
+  uint64_t row0 = b * j.batch + w * 64;
+  uint64_t bend = (b + 1) * (uint64_t)j.batch;
+  if (bend > j.n_rows) bend = j.n_rows;
+  unsigned long long v = 0;
+  uint32_t rows = 0, nulls = 0;
+  if (row0 < bend) {
+    rows = bend - row0 < 64 ? (uint32_t)(bend - row0) : 64;
+    uint64_t sw = row0 >> 6;
+    uint32_t sh = row0 & 63;
+    unsigned long long lo = j.vbits[sw];
+    unsigned long long hi = (sh && ((sw + 1) * 64 < j.n_rows)) ? j.vbits[sw + 1] : 0;
+    v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    if (rows < 64) v &= (1ull << rows) - 1;
+    nulls = live ? rows - (uint32_t)__builtin_popcountll(v) : 0;
+  }
+  if (live) j.validity[t] = v;
+  const uint64_t b0 = __shfl((unsigned long long)b, 0);
+  if (__ballot(b != b0) == 0) {
+    for (int o = 32; o; o >>= 1) nulls += __shfl_xor(nulls, o);
+    if ((threadIdx.x & 63) == 0 && nulls) atomicAdd(&j.null_counts[b0], (unsigned long long)nulls);
+  } else if (nulls) {
+    atomicAdd(&j.null_counts[b], (unsigned long long)nulls);
   }
 }
 

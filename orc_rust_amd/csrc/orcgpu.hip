@@ -301,6 +301,8 @@ struct Plan {
   uint64_t n_nullcount_slots = 0, n_chartot_slots = 0;
   std::vector<int> pending_gathers;
   uint64_t dictjobs_off = 0;           // device copy of the DictJob table (scratch offset)
+  uint64_t presjobs_off = 0;           // device copy of the PresJob table
+  std::vector<PresJob> presjobs;
   std::vector<DictJob> dictjobs;       // host copy, same order as pending_gathers
   std::vector<DecompStream> decomp;  // compressed streams to expand before anything else  // indices into cols: dictionary string columns waiting for their gather
   uint32_t new_scalar(uint64_t v) {
