@@ -258,6 +258,24 @@ extern "C" __global__ void __launch_bounds__(256) space16_kernel(const int16_t* 
 extern "C" __global__ void __launch_bounds__(256) space32_kernel(const int32_t* d, const unsigned long long* vb, const uint32_t* rk, int32_t* o, uint64_t n) { space_body(d, vb, rk, o, n); }
 extern "C" __global__ void __launch_bounds__(256) space64_kernel(const int64_t* d, const unsigned long long* vb, const uint32_t* rk, int64_t* o, uint64_t n) { space_body(d, vb, rk, o, n); }
 
+// the same for all fixed-width columns of a call (blockIdx.y = column)
+struct SpaceJob {
+  const void* dense;
+  const unsigned long long* vbits;
+  const uint32_t* rank;
+  void* out;
+  uint64_t n_rows;
+  uint32_t width, pad;
+};
+extern "C" __global__ void __launch_bounds__(256) space_multi_kernel(const SpaceJob* jobs) {
+  const SpaceJob j = jobs[blockIdx.y];
+  if ((uint64_t)blockIdx.x * 256 >= j.n_rows) return;
+  if (j.width == 8) space_body((const int64_t*)j.dense, j.vbits, j.rank, (int64_t*)j.out, j.n_rows);
+  else if (j.width == 4) space_body((const int32_t*)j.dense, j.vbits, j.rank, (int32_t*)j.out, j.n_rows);
+  else if (j.width == 2) space_body((const int16_t*)j.dense, j.vbits, j.rank, (int16_t*)j.out, j.n_rows);
+  else space_body((const int8_t*)j.dense, j.vbits, j.rank, (int8_t*)j.out, j.n_rows);
+}
+
 // Float/Double without nulls: plain copy of the raw little-endian stream (float.rs:70-74).
 extern "C" __global__ void __launch_bounds__(256) copy_bytes_kernel(const uint8_t* src, uint8_t* dst, uint64_t n) {
   uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;

@@ -303,6 +303,8 @@ struct Plan {
   uint64_t dictjobs_off = 0;           // device copy of the DictJob table (scratch offset)
   uint64_t presjobs_off = 0;           // device copy of the PresJob table
   std::vector<PresJob> presjobs;
+  uint64_t spacejobs_off = 0;          // device copy of the SpaceJob table
+  std::vector<SpaceJob> spacejobs;
   std::vector<DictJob> dictjobs;       // host copy, same order as pending_gathers
   std::vector<DecompStream> decomp;  // compressed streams to expand before anything else  // indices into cols: dictionary string columns waiting for their gather
   uint32_t new_scalar(uint64_t v) {
