@@ -446,7 +446,17 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
         bool keep = false;
         if (fl) {
           if (!pfl) {
+            // ... unless the weak predecessor's exit lies in front of this block's verified header and its
+            // chain arrives exactly there: then shorter runs precede the full run the search found
             keep = true;
+            if (pex < e && e < RLE_BLK) {
+              uint64_t from = (uint64_t)lb * RLE_BLK + pex, target = (uint64_t)lb * RLE_BLK + e;
+              bool hits;
+              if (j->codec == CODEC_RLE2) hits = chain_hits<CODEC_RLE2>(data, len, from, target, j->is_signed, j->nbits);
+              else if (j->codec == CODEC_RLE1) hits = chain_hits<CODEC_RLE1>(data, len, from, target, j->is_signed, j->nbits);
+              else hits = chain_hits<CODEC_BYTE>(data, len, from, target, false, 8);
+              keep = !hits;
+            }
           } else if (!panc && e < pex && e < RLE_BLK) {
             uint64_t from = (uint64_t)lb * RLE_BLK + e, target = (uint64_t)lb * RLE_BLK + pex;
             if (j->codec == CODEC_RLE2) keep = chain_hits<CODEC_RLE2>(data, len, from, target, j->is_signed, j->nbits);
