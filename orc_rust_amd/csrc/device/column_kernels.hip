@@ -347,10 +347,22 @@ extern "C" __global__ void __launch_bounds__(256) timestamp_kernel(const int64_t
     }
     int64_t sse = (int64_t)((uint64_t)secs[d] + (uint64_t)base);
     int64_t s = (sse < 0 && nn > 999999) ? sse - 1 : sse;
-    __int128 ns = (__int128)s * 1000000000 + (__int128)nn;
-    const int64_t per = unit == 0 ? 1000000000 : (unit == 1 ? 1000000 : (unit == 2 ? 1000 : 1));
-    __int128 q = ns / per;
-    bool bad = (ns % per) != 0 || q > (__int128)INT64_MAX || q < (__int128)INT64_MIN;
+    // ns = s * 1e9 + nn, then ns / per with `per` (1, 1e3, 1e6 or 1e9 ns per unit) dividing 1e9: the
+    // remainder of ns is that of nn, and an exact quotient is s * (1e9 / per) + nn / per -- no 128-bit
+    // division (which costs hundreds of instructions per row), constants per unit
+    uint64_t qn, rem;
+    int64_t m;
+    if (unit == 3) {
+      qn = nn, rem = 0, m = 1000000000;
+    } else if (unit == 2) {
+      qn = nn / 1000, rem = nn - qn * 1000, m = 1000000;
+    } else if (unit == 1) {
+      qn = nn / 1000000, rem = nn - qn * 1000000, m = 1000;
+    } else {
+      qn = nn / 1000000000, rem = nn - qn * 1000000000, m = 1;
+    }
+    const __int128 q = (__int128)s * m + (__int128)qn;
+    bool bad = rem != 0 || q > (__int128)INT64_MAX || q < (__int128)INT64_MIN;
     if (bad) report_row(err, i, ORC_E_TIMESTAMP);
     r = (int64_t)q;
   }
