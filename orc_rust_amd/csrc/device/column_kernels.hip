@@ -174,42 +174,9 @@ extern "C" __global__ void __launch_bounds__(256) scan_apply_kernel(uint32_t* ou
   if (i < n) out[i] += tile_sum[i >> 10];
 }
 
-// Per-batch validity bitmaps + null counts.  One thread per output word of a batch.
-// out layout: batch b at word offset b * words_per_batch.
-extern "C" __global__ void __launch_bounds__(256) validity_batches_kernel(const unsigned long long* vbits, uint64_t n_rows, uint32_t batch,
-                                                                           uint32_t words_per_batch, unsigned long long* out,
-                                                                           unsigned long long* null_counts, uint64_t n_out_words) {
-  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = t < n_out_words;
-  if (!live) t = n_out_words - 1;  // stays in the wavefront for the reduction below, contributes nothing
-  uint64_t b = t / words_per_batch, w = t % words_per_batch;
-  uint64_t row0 = b * batch + w * 64;
-  uint64_t bend = (b + 1) * (uint64_t)batch;
-  if (bend > n_rows) bend = n_rows;
-  unsigned long long v = 0;
-  uint32_t rows = 0, nulls = 0;
-  if (row0 < bend) {
-    rows = bend - row0 < 64 ? (uint32_t)(bend - row0) : 64;
-    uint64_t sw = row0 >> 6;
-    uint32_t sh = row0 & 63;
-    unsigned long long lo = vbits[sw];
-    unsigned long long hi = (sh && ((sw + 1) * 64 < n_rows)) ? vbits[sw + 1] : 0;
-    v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
-    if (rows < 64) v &= (1ull << rows) - 1;
-    nulls = live ? rows - (uint32_t)__builtin_popcountll(v) : 0;
-  }
-  if (live) out[t] = v;
-  // one atomic per wavefront when its 64 words belong to one batch (the common case), not one per word
-  const uint64_t b0 = __shfl((unsigned long long)b, 0);
-  if (__ballot(b != b0) == 0) {
-    for (int o = 32; o; o >>= 1) nulls += __shfl_xor(nulls, o);
-    if ((threadIdx.x & 63) == 0 && nulls) atomicAdd(&null_counts[b0], (unsigned long long)nulls);
-  } else if (nulls) {
-    atomicAdd(&null_counts[b], (unsigned long long)nulls);
-  }
-}
-
-// the same for all columns of a call (blockIdx.y = column)
+// Per-batch validity bitmaps + null counts of all columns of a call (blockIdx.y = column).  One thread per
+// output word of a batch; out layout: batch b at word offset b * words_per_batch; one atomic per wavefront
+// when its 64 words belong to one batch (the common case).
 extern "C" __global__ void __launch_bounds__(256) pres_validity_kernel(const PresJob* jobs) {
   const PresJob j = jobs[blockIdx.y];
   if ((uint64_t)blockIdx.x * 256 >= j.n_out_words) return;
@@ -253,12 +220,8 @@ __device__ __forceinline__ void space_body(const T* dense, const unsigned long l
   if ((word >> bit) & 1) v = dense[(uint64_t)rank[i >> 6] + __builtin_popcountll(word & ((1ull << bit) - 1))];
   out[i] = v;
 }
-extern "C" __global__ void __launch_bounds__(256) space8_kernel(const int8_t* d, const unsigned long long* vb, const uint32_t* rk, int8_t* o, uint64_t n) { space_body(d, vb, rk, o, n); }
-extern "C" __global__ void __launch_bounds__(256) space16_kernel(const int16_t* d, const unsigned long long* vb, const uint32_t* rk, int16_t* o, uint64_t n) { space_body(d, vb, rk, o, n); }
-extern "C" __global__ void __launch_bounds__(256) space32_kernel(const int32_t* d, const unsigned long long* vb, const uint32_t* rk, int32_t* o, uint64_t n) { space_body(d, vb, rk, o, n); }
-extern "C" __global__ void __launch_bounds__(256) space64_kernel(const int64_t* d, const unsigned long long* vb, const uint32_t* rk, int64_t* o, uint64_t n) { space_body(d, vb, rk, o, n); }
 
-// the same for all fixed-width columns of a call (blockIdx.y = column)
+// all fixed-width columns of a call in one launch (blockIdx.y = column)
 struct SpaceJob {
   const void* dense;
   const unsigned long long* vbits;
@@ -367,11 +330,6 @@ extern "C" __global__ void __launch_bounds__(256) timestamp_kernel(const int64_t
     r = (int64_t)q;
   }
   out[i] = r;
-}
-
-// scalars[dst] = ceil(scalars[src] / 8): bytes of a Boolean DATA bit stream needed for the non-null rows
-extern "C" __global__ void ceil_div8_kernel(uint64_t* scalars, uint32_t src, uint32_t dst) {
-  if (threadIdx.x == 0) scalars[dst] = (scalars[src] + 7) / 8;
 }
 
 // Float/Double: read_exact of `needed` values must fit in the stream (float.rs:70-74 -> IoError).

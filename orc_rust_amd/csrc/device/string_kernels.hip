@@ -116,26 +116,6 @@ extern "C" __global__ void __launch_bounds__(256) batch_base_kernel(const unsign
   if (threadIdx.x == 0) *total = carry_s;
 }
 
-// ---- dictionary -> Utf8 materialisation: one lane per row, bytes of the entry copied to the row's slot
-extern "C" __global__ void __launch_bounds__(256) dict_gather_kernel(const int32_t* keys, const int32_t* lens, const int32_t* offsets,
-                                                                      const unsigned long long* charbase, const int32_t* dict_off,
-                                                                      const uint8_t* dict_bytes, uint8_t* out, uint64_t n_rows, uint32_t batch) {
-  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_rows) return;
-  int32_t len = lens[i];
-  if (!len) return;
-  uint64_t b = i / batch;
-  uint64_t dst = charbase[b] + (uint64_t)(uint32_t)offsets[b * ((uint64_t)batch + 1) + (i - b * batch)];
-  const uint8_t* src = dict_bytes + dict_off[keys[i]];
-  uint8_t* d = out + dst;
-  int32_t k = 0;
-  for (; k + 8 <= len; k += 8) {
-    uint64_t v = ld_u64(src + k);
-    __builtin_memcpy(d + k, &v, 8);
-  }
-  for (; k < len; k++) d[k] = src[k];
-}
-
 // ---- dictionary-encoded strings, all columns of a call in one launch ------------------------------------------
 // DictionaryStringArrayDecoder::next_batch (array_decoder/string.rs:204-224) per batch: keys
 // (bounds-checked) -> lengths -> int32 offsets restarting at 0 -> gather of the entries.
