@@ -18,3 +18,5 @@ unset COMP
 cd $R
 for c in none snappy lz4 zlib zstd; do COMP=$c python profiles/bench_c3.py 2>/dev/null | tail -1 > $O/c3_line_$c.json; done
 ls -la $O
+for c in none zstd; do COMP=$c python profiles/bench_mixed.py 2>/dev/null | tail -1 > $O/mixed_line_$c.json; done
+ls $O | head -40

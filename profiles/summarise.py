@@ -7,6 +7,7 @@ for name, dst in (('c2_stats', 'r01_c2_kernel_stats.csv'), ('c3_none', 'r01_c3_n
 shutil.copy(f'{O}/bench_line.json', f'{P}/r01_bench_line.json')
 json.dump({k: json.load(open(f'{O}/bench_{k}.json')) for k in ('direct', 'delta', 'arange')}, open(f'{P}/r01_c2_variants.json', 'w'), indent=1)
 json.dump({c: json.loads(open(f'{O}/c3_line_{c}.json').read()) for c in ('none', 'snappy', 'lz4', 'zlib', 'zstd')}, open(f'{P}/r01_c3_lines.json', 'w'), indent=1)
+json.dump({c: json.loads(open(f'{O}/mixed_line_{c}.json').read()) for c in ('none', 'zstd')}, open(f'{P}/r01_mixed_lines.json', 'w'), indent=1)
 res = {}
 for cnt, d in (('FETCH_SIZE', 'c2_fetch'), ('WRITE_SIZE', 'c2_write')):
     acc = collections.defaultdict(list)
