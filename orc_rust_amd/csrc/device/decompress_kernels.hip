@@ -667,7 +667,7 @@ __device__ __forceinline__ void decompress_chunks_body(ChunkDesc* chunks, uint32
   } else if (FAMILY == 1 && d.kind == 1) {
     bad = inflate_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, *tables, lz);
   } else if (FAMILY == 2 && d.kind == 5) {
-    bad = zstd_wave(d.src, d.src_len, d.dst, d.dst_cap, d.scratch, lane, &out_len, *tables, lz);
+    bad = zstd_wave(d.src, d.src_len, d.dst, d.dst_cap, d.scratch, lane, &out_len, *tables, lz PROF_ARG);
   } else {
     bad = 1;  // unknown compression kind
   }

@@ -16,14 +16,20 @@ __device__ const uint8_t Z_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
 __device__ const uint32_t Z_ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
 __device__ const uint8_t Z_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
 
-// backward bit stream: `bits` = number of unread bits, reading proceeds from bit (bits-1) down
+// backward bit stream: `bits` = number of unread bits, reading proceeds from bit (bits-1) down.
+// A 64-bit window of the stream is kept in a register and refilled only when a read leaves it: a
+// memory round trip per 7 bytes consumed instead of one per symbol.
 struct RBits {
   const uint8_t* p;
   long bits;
+  uint64_t win;   // stream bits [wbit, wbit + 64)
+  long wbit;      // multiple of 8; -1: nothing loaded
 };
 __device__ __forceinline__ bool rb_init(RBits& r, const uint8_t* p, uint32_t n) {
   r.p = p;
   r.bits = 0;
+  r.win = 0;
+  r.wbit = -1;
   if (n == 0 || p[n - 1] == 0) return false;
   int hb = 31 - __builtin_clz((uint32_t)p[n - 1]);
   r.bits = (long)(n - 1) * 8 + hb;
@@ -35,7 +41,18 @@ __device__ __forceinline__ uint64_t rb_read(RBits& r, uint32_t nb) {
   uint64_t v;
   uint64_t mask = nb >= 64 ? ~0ull : ((1ull << nb) - 1);
   if (start >= 0) {
-    v = (ld_u64(r.p + (start >> 3)) >> (start & 7)) & mask;
+    if (nb > 56) {
+      v = (ld_u64(r.p + (start >> 3)) >> (start & 7)) & mask;  // (never: fields are at most 32 bits wide)
+    } else {
+      if (r.wbit < 0 || start < r.wbit || start + (long)nb > r.wbit + 64) {
+        // put the window's top just above this read: the following (lower) reads find their bits in it
+        long byte = ((start + (long)nb + 7) >> 3) - 8;
+        if (byte < 0) byte = 0;
+        r.win = ld_u64(r.p + byte);
+        r.wbit = byte * 8;
+      }
+      v = (r.win >> (start - r.wbit)) & mask;
+    }
   } else if (r.bits > 0) {
     // the low (-start) bits lie before the stream and read as zero
     uint64_t have = ld_u64(r.p) & ((1ull << r.bits) - 1);
@@ -219,6 +236,114 @@ __device__ __forceinline__ int huf_decode_stream_dev(const uint16_t* tab, int mb
   return r.bits != -(long)mb;
 }
 
+// Huffman streams decoded by MANY lanes each (16 per stream for the usual four streams, 64 for a single
+// one).  A stream is a chain of prefix codes read downwards from its top bit; lane k of a stream starts
+// at bit top - k*B (not a code boundary in general), decodes down to the start of the next lane's
+// segment and reports where it crossed it.  Prefix codes re-synchronise within a few symbols, so after
+// handing every lane its predecessor's crossing point once or twice nothing changes any more (the
+// loop runs until then: exact whatever the data, at worst as slow as one lane per stream).  Symbol
+// counts are then prefix-summed per stream and a last pass writes the symbols.
+// downward bit cursor for the Huffman streams: `pos` = code boundary (bits of the stream below it are
+// unread), `w` holds the bits just below pos left-aligned (bit pos-1 at bit 63), `avail` of them valid;
+// bits below the start of the stream read as zero.
+struct HBits {
+  const uint8_t* p;
+  uint64_t w;
+  int pos, avail;
+};
+__device__ __forceinline__ void hb_seek(HBits& h, int pos) {
+  h.pos = pos;
+  const int bytepos = (pos + 7) >> 3;  // first byte at or above pos
+  uint64_t v;
+  if (bytepos >= 8) v = ld_u64(h.p + bytepos - 8);
+  else v = bytepos > 0 ? ld_u64(h.p) << (8 * (8 - bytepos)) : 0;
+  const int waste = 8 * bytepos - pos;  // 0..7 bits at the top that lie above pos
+  h.w = v << waste;
+  h.avail = 64 - waste;
+}
+
+__device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const uint8_t* sp, uint32_t sn, uint8_t* out, uint32_t outn, uint32_t k,
+                                              uint32_t lps, bool on) {
+  int bad = 0;
+  int top = 0;
+  if (on) {
+    RBits r;
+    if (!rb_init(r, sp, sn)) bad = 1;
+    top = (int)r.bits;
+  }
+  HBits h{sp, 0, 0, 0};
+  const int B = (top + (int)lps - 1) / (int)lps;
+  int pk = top - (int)k * B, pn = k + 1 == lps ? 0 : top - (int)(k + 1) * B;
+  if (pk < 0) pk = 0;
+  if (pn < 0) pn = 0;
+  int start = pk, endpos = pk;
+  uint32_t cnt = 0;
+  const bool work = on && !bad;
+  for (uint32_t round = 0; round < lps; round++) {
+    cnt = 0;
+    endpos = start;
+    if (work && start > pn) {
+      hb_seek(h, start);
+      while (h.pos > pn) {
+        const uint32_t e = tab[h.w >> (64 - mb)];
+        const int nb = (int)(e >> 8);
+        if (nb == 0) {  // not a table zstd builds: no progress possible
+          bad = 1;
+          break;
+        }
+        cnt++;
+        h.w <<= nb;
+        h.pos -= nb;
+        h.avail -= nb;
+        if (h.avail < mb) hb_seek(h, h.pos);
+      }
+      endpos = h.pos;
+    }
+    // predecessor's crossing point -> this lane's start (lane 0 of a stream starts at the top)
+    const int prev = __shfl_up(endpos, 1);
+    bool changed = false;
+    if (k > 0 && work && prev != start) {
+      start = prev;
+      changed = true;
+    }
+    if (!__ballot(changed)) break;
+  }
+  // symbols before this lane inside its stream
+  uint32_t incl = cnt;
+  for (uint32_t o = 1; o < lps; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o);
+    if (k >= o) incl += t;
+  }
+  const uint32_t glast = ((threadIdx.x & 63) & ~(lps - 1)) + lps - 1;
+  const uint32_t total = __shfl(incl, glast);
+  const int last_end = __shfl(endpos, glast);
+  if (work && (total != outn || last_end != 0)) bad = 1;
+  if (work && !bad && start > pn) {
+    // symbols leave eight at a time (one 8-byte store instead of eight scattered single-byte ones: the
+    // stores of a block used to take longer to drain than the decoding itself)
+    uint32_t i = incl - cnt, nacc = 0;
+    uint64_t acc = 0;
+    hb_seek(h, start);
+    while (h.pos > pn) {
+      const uint32_t e = tab[h.w >> (64 - mb)];
+      const int nb = (int)(e >> 8);
+      acc |= (uint64_t)(e & 0xff) << (8 * nacc);
+      if (++nacc == 8) {
+        __builtin_memcpy(out + i, &acc, 8);
+        i += 8;
+        nacc = 0;
+        acc = 0;
+      }
+      h.w <<= nb;
+      h.pos -= nb;
+      h.avail -= nb;
+      if (h.avail < mb) hb_seek(h, h.pos);
+    }
+    for (uint32_t t = 0; t < nacc; t++) out[i + t] = (uint8_t)(acc >> (8 * t));
+  }
+  return bad;
+}
+
 struct ZState {
   int huf_valid, huf_bits;
   int ll_valid, of_valid, ml_valid;
@@ -228,7 +353,7 @@ struct ZState {
 
 // literals section: returns bytes consumed (<0 error); *lit/*litn describe the decoded literals
 __device__ __forceinline__ long z_literals_dev(ZState& z, DecompLds& L, const uint8_t* p, uint32_t n, uint8_t* scratch, const uint8_t** lit,
-                                               uint32_t* litn, uint32_t lane) {
+                                               uint32_t* litn, uint32_t lane PROF_PARM) {
   if (n < 1) return -1;
   uint32_t type = p[0] & 3, sf = (p[0] >> 2) & 3;
   uint32_t regen, comp = 0, hdr;
@@ -339,16 +464,19 @@ __device__ __forceinline__ long z_literals_dev(ZState& z, DecompLds& L, const ui
       used = 1 + hb;
       wave_sync();
     }
+    PROF_MARK(5);
     if (huf_build_dev(L.z.huf, &z.huf_bits, L.z.weights, nw, lane)) return -1;
+    PROF_MARK(6);
     z.huf_valid = 1;
     q += used;
     qn -= used;
   } else if (!z.huf_valid) {
     return -1;
   }
+  PROF_MARK(7);
   int bad = 0;
   if (streams == 1) {
-    if (lane == 0) bad = huf_decode_stream_dev(L.z.huf, z.huf_bits, q, qn, scratch, regen);
+    bad = huf_decode_par(L.z.huf, z.huf_bits, q, qn, scratch, regen, lane, 64, true);
   } else {
     if (qn < 6) return -1;
     uint32_t s1 = q[0] | (q[1] << 8), s2 = q[2] | (q[3] << 8), s3 = q[4] | (q[5] << 8);
@@ -357,13 +485,13 @@ __device__ __forceinline__ long z_literals_dev(ZState& z, DecompLds& L, const ui
     uint32_t seg = (regen + 3) / 4;
     if (seg * 3 > regen) return -1;
     const uint8_t* b = q + 6;
-    if (lane < 4) {
-      uint32_t so = lane == 0 ? 0 : (lane == 1 ? s1 : (lane == 2 ? s1 + s2 : s1 + s2 + s3));
-      uint32_t sl = lane == 0 ? s1 : (lane == 1 ? s2 : (lane == 2 ? s3 : s4));
-      uint32_t on = lane < 3 ? seg : regen - 3 * seg;
-      bad = huf_decode_stream_dev(L.z.huf, z.huf_bits, b + so, sl, scratch + lane * seg, on);
-    }
+    const uint32_t st = lane >> 4;  // stream of this lane (16 lanes each)
+    uint32_t so = st == 0 ? 0 : (st == 1 ? s1 : (st == 2 ? s1 + s2 : s1 + s2 + s3));
+    uint32_t sl = st == 0 ? s1 : (st == 1 ? s2 : (st == 2 ? s3 : s4));
+    uint32_t on = st < 3 ? seg : regen - 3 * seg;
+    bad = huf_decode_par(L.z.huf, z.huf_bits, b + so, sl, scratch + st * seg, on, lane & 15, 16, true);
   }
+  PROF_MARK(8);
   if (__ballot(bad != 0)) return -1;
   wave_fence();
   *lit = scratch;
@@ -408,10 +536,12 @@ __device__ __forceinline__ long z_seq_table_dev(FseEnt* t, int* valid, int* log_
 // one compressed block; returns the new output size or -1
 // (returns 0 or -1; the output goes through the LDS window `o`; match distances count from frame_start)
 __device__ __forceinline__ long z_block_dev(ZState& z, DecompLds& L, const uint8_t* p, uint32_t n, LzOut& o, uint64_t frame_start, uint64_t cap,
-                                            uint8_t* scratch, uint32_t lane) {
+                                            uint8_t* scratch, LzLds Z, uint32_t lane PROF_PARM) {
   const uint8_t* lit = nullptr;
   uint32_t litn = 0;
-  long used = z_literals_dev(z, L, p, n, scratch, &lit, &litn, lane);
+  PROF_MARK(10);
+  long used = z_literals_dev(z, L, p, n, scratch, &lit, &litn, lane PROF_ARG);
+  PROF_MARK(11);
   if (used < 0) return -1;
   const uint8_t* q = p + used;
   uint32_t qn = n - (uint32_t)used;
@@ -456,6 +586,24 @@ __device__ __forceinline__ long z_block_dev(ZState& z, DecompLds& L, const uint8
     uint32_t sl = (uint32_t)rb_read(r, (uint32_t)z.ll_log);
     uint32_t so = (uint32_t)rb_read(r, (uint32_t)z.of_log);
     uint32_t sm = (uint32_t)rb_read(r, (uint32_t)z.ml_log);
+    PROF_MARK(12);
+    // The FSE state machine is serial, the copies are not: sequences are decoded one after the other into
+    // the group table (literal part, match part) and executed 60+ elements at a time by lz_group_run
+    // (wave scan -> output positions, independent copies in parallel).  Literals come from `lit`.
+    LzIn lin{lit, litn, Z.stage, 0};
+    lzin_stage(lin, lp, lane);
+    LzGroup G{0, 0, 0, 0};
+    uint32_t gn = 0;
+    uint64_t vout = o.out;  // output position once everything filed has been executed
+    auto run_group = [&]() -> int {
+      lds_order();
+      G.len = lane < gn ? Z.g_len[lane] : 0;
+      G.off = lane < gn ? Z.g_off[lane] : 0;
+      G.src = lane < gn ? Z.g_src[lane] : 0;
+      G.n = gn;
+      gn = 0;
+      return lz_group_run(G, lin, o, cap, lane PROF_ARG);
+    };
     for (uint32_t i = 0; i < nseq; i++) {
       FseEnt el = L.z.ll[sl], eo = L.z.of[so], em = L.z.ml[sm];
       uint32_t oc = eo.sym, mc = em.sym, lc = el.sym;
@@ -482,11 +630,34 @@ __device__ __forceinline__ long z_block_dev(ZState& z, DecompLds& L, const uint8
         }
       }
       if (offset == 0) return -1;
-      if ((uint64_t)lp + llen > litn || o.out + llen + mlen > cap) return -1;
-      lz_literal(o, lit + lp, llen, lane);
+      if ((uint64_t)lp + llen > litn || vout + llen + mlen > cap) return -1;
+      if (offset > vout + llen - frame_start) return -1;
+      if (gn > 62 && run_group()) return -1;
+      if (llen > 64) {
+        if (run_group()) return -1;
+        lz_literal(o, lit + lp, llen, lane);
+      } else if (llen) {
+        if (lane == 0) {
+          Z.g_len[gn] = llen;
+          Z.g_off[gn] = 0;
+          Z.g_src[gn] = lp;
+        }
+        gn++;
+      }
       lp += llen;
-      if (offset > o.out - frame_start) return -1;
-      lz_match(o, (uint32_t)offset, mlen, lane);
+      if (mlen > 64 || offset > 0xffffffffull) {
+        if (run_group()) return -1;
+        if (offset > 0xffffffffull) return -1;
+        lz_match(o, (uint32_t)offset, mlen, lane);
+      } else {
+        if (lane == 0) {
+          Z.g_len[gn] = mlen;
+          Z.g_off[gn] = (uint32_t)offset;
+          Z.g_src[gn] = 0;
+        }
+        gn++;
+      }
+      vout += llen + mlen;
       if (i + 1 < nseq) {
         sl = el.base + (uint32_t)rb_read(r, el.nb);
         sm = em.base + (uint32_t)rb_read(r, em.nb);
@@ -494,15 +665,18 @@ __device__ __forceinline__ long z_block_dev(ZState& z, DecompLds& L, const uint8
         if (r.bits < 0) return -1;
       }
     }
+    if (run_group()) return -1;
     if (r.bits != 0) return -1;
   }
+  PROF_MARK(13);
   if (o.out + (litn - lp) > cap) return -1;
   lz_literal(o, lit + lp, litn - lp, lane);
+  PROF_MARK(14);
   return 0;
 }
 
 __device__ __forceinline__ int zstd_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* scratch, uint32_t lane,
-                                          uint32_t* out_len, DecompLds& L, LzLds Z) {
+                                          uint32_t* out_len, DecompLds& L, LzLds Z PROF_PARM) {
   uint32_t pos = 0;
   LzOut o{Z.ring, Z.rsize - 1, dst, 0, 0};
   while (pos < n) {
@@ -563,7 +737,7 @@ __device__ __forceinline__ int zstd_wave(const uint8_t* src, uint32_t n, uint8_t
         pos += 1;
       } else if (bt == 2) {
         if ((uint64_t)pos + bs > n || bs > 128 * 1024) return 1;
-        if (z_block_dev(z, L, src + pos, bs, o, frame_start, cap, scratch, lane) < 0) return 1;
+        if (z_block_dev(z, L, src + pos, bs, o, frame_start, cap, scratch, Z, lane PROF_ARG) < 0) return 1;
         pos += bs;
       } else {
         return 1;
