@@ -17,13 +17,29 @@ def _sources():
     return out
 
 
+def _fresh(srcs):
+    return os.path.exists(SO) and all(os.path.getmtime(s) <= os.path.getmtime(SO) for s in srcs)
+
+
 def build(force=False):
+    """Returns the path of liborcgpu.so, compiling it first when it is missing or older than a source.
+    Safe with several ranks starting at once: one of them builds (file lock), into a temporary name that
+    replaces the library atomically; the others wait and then find it fresh."""
+    import fcntl
     srcs = _sources()
-    if not force and os.path.exists(SO) and all(os.path.getmtime(s) <= os.path.getmtime(SO) for s in srcs):
+    if not force and _fresh(srcs):
         return SO
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO, os.path.join(CSRC, "orcgpu.hip")]
-    subprocess.check_call(cmd, cwd=CSRC)
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not _fresh(srcs):
+                hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+                tmp = SO + ".tmp.%d" % os.getpid()
+                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", tmp, os.path.join(CSRC, "orcgpu.hip")]
+                subprocess.check_call(cmd, cwd=CSRC)
+                os.replace(tmp, SO)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return SO
 
 
