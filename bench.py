@@ -202,7 +202,7 @@ def main():
                      "kernel_ms": round(exp_avg_ms, 4)},
     }
     if rank == 0:
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(stripes)
         print(json.dumps(out))
     if dist is not None:
