@@ -48,18 +48,34 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Inclusive scan over the 64 lanes with DPP adds (row shifts inside each row of 16 lanes, then the
+// row totals broadcast onwards): six VALU instructions, no trip through the LDS crossbar that
+// `__shfl_up` (ds_bpermute) would take six times in a dependent chain.
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t t = __shfl_up(v, o);
-    if ((int)lane >= o) v += t;
-  }
-  return v;
+  (void)lane;
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+  return (uint32_t)x;
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {  // the two halves moved by the same DPP pattern (0 where it has no source)
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWS, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROWS, 0xf, false);
+  return lo | ((uint64_t)hi << 32);
 }
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, uint32_t lane) {
-  for (int o = 1; o < 64; o <<= 1) {
-    uint64_t t = __shfl_up(v, o);
-    if ((int)lane >= o) v += t;
-  }
+  (void)lane;
+  v += dpp_u64<0x111, 0xf>(v);
+  v += dpp_u64<0x112, 0xf>(v);
+  v += dpp_u64<0x114, 0xf>(v);
+  v += dpp_u64<0x118, 0xf>(v);
+  v += dpp_u64<0x142, 0xa>(v);
+  v += dpp_u64<0x143, 0xc>(v);
   return v;
 }
 
@@ -408,7 +424,8 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
             pre[k] = run;
           }
         }
-        uint64_t incl = wave_incl_scan_u64(run, lane);
+        // narrow deltas: the 510 of them sum to less than 2^32, the cheaper 32-bit scan will do
+        uint64_t incl = w <= 16 ? (uint64_t)wave_incl_scan_u32((uint32_t)run, lane) : wave_incl_scan_u64(run, lane);
         uint64_t excl = incl - run;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
