@@ -15,6 +15,7 @@
 // All stream buffers in HBM carry >= ORC_PAD bytes of readable slack after their last byte, so
 // 8-byte unaligned loads may run past the logical end (their extra bytes are never used).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -48,6 +49,11 @@ __device__ __forceinline__ void* as_global(void* p) {
   __attribute__((address_space(1))) uint8_t* g = (__attribute__((address_space(1))) uint8_t*)p;
   asm volatile("" : "+v"(g));
   return (void*)g;
+}
+
+template <typename T>
+__device__ __forceinline__ T* glob(T* p) {  // typed as_global()
+  return (T*)as_global((void*)const_cast<typename std::remove_const<T>::type*>(p));
 }
 
 __device__ __forceinline__ uint64_t ld_u64(const uint8_t* p) {

@@ -136,6 +136,21 @@ struct DictJob {
   uint32_t dict_n_idx;              // scalar holding the dictionary size
   uint32_t pad;
 };
+__device__ __forceinline__ DictJob dict_job(const DictJob* jobs, uint32_t i) {
+  DictJob j = jobs[i];  // every pointer in it is device global memory: see as_global()
+  j.dense = glob(j.dense);
+  j.vbits = glob(j.vbits);
+  j.rank = glob(j.rank);
+  j.doff = glob(j.doff);
+  j.dbytes = glob(j.dbytes);
+  j.offsets = glob(j.offsets);
+  j.keys = glob(j.keys);
+  j.chartot = glob(j.chartot);
+  j.err = glob(j.err);
+  j.out_chars = glob(j.out_chars);
+  j.total_out = glob(j.total_out);
+  return j;
+}
 #define DICT_TILE 8192u
 #define DICT_DOFF_LDS 2048u
 
@@ -147,7 +162,7 @@ extern "C" __global__ void __launch_bounds__(256) dict_rows_kernel(const DictJob
   __shared__ int32_t doffc[DICT_DOFF_LDS + 1];
   __shared__ uint64_t wsum[4];
   __shared__ uint64_t tbase[256];
-  const DictJob j = jobs[blockIdx.y];
+  const DictJob j = dict_job(jobs, blockIdx.y);
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   if (b >= j.n_batches) return;
   const uint64_t dict_n = scalars[j.dict_n_idx];
@@ -243,7 +258,7 @@ extern "C" __global__ void __launch_bounds__(256) dict_rows_kernel(const DictJob
 extern "C" __global__ void __launch_bounds__(256) dict_base_kernel(const DictJob* jobs) {
   __shared__ uint64_t wsum[4];
   __shared__ uint64_t carry_s;
-  const DictJob j = jobs[blockIdx.x];
+  const DictJob j = dict_job(jobs, blockIdx.x);
   unsigned long long* charbase = j.chartot + j.n_batches;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
@@ -276,7 +291,7 @@ extern "C" __global__ void __launch_bounds__(256) dict_gather2_kernel(const Dict
   __shared__ __attribute__((aligned(16))) uint8_t chars[DICT_CHARS_LDS + 16];
   __shared__ int32_t doffc[DICT_DOFF_LDS + 1];
   __shared__ uint8_t dbc[DICT_BYTES_LDS];
-  const DictJob j = jobs[blockIdx.y];
+  const DictJob j = dict_job(jobs, blockIdx.y);
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   if (b >= j.n_batches) return;
   const uint64_t total = j.chartot[b];
