@@ -326,6 +326,31 @@ def test_corruption_sweep(enc, typ, seed):
             res.free()
 
 
+@pytest.mark.parametrize("batch", [1, 63, 20000, 100000])
+def test_unusual_batch_sizes(batch):
+    """Batches smaller than a validity word and larger than the kernels' tiles (dictionary rows are
+    scanned in tiles of 8192): same bytes as the oracle."""
+    STRING, LENGTH, DICT = 7, 2, 3
+    n = 70000 if batch > 1 else 300
+    rng = np.random.default_rng(batch)
+    present = (rng.random(n) >= 0.2).astype(np.uint8)
+    k = int(present.sum())
+    dwords = [b"AIR", b"FOB", b"MAIL", b"RAIL", b"REG AIR", b"SHIP", b"TRUCK", b""]
+    cols = [col(1, STRING, enc=3, dictionary_size=len(dwords)), col(2, LONG), col(3, STRING), col(4, BOOLEAN, enc=0)]
+    idx = rng.integers(0, len(dwords), k)
+    streams = [(1, PRESENT, gen.boolean(present)), (1, DATA, gen.rle2(rng.integers(0, len(dwords), k), signed=False)),
+               (1, LENGTH, gen.rle2(np.array([len(w) for w in dwords], dtype=np.int64), signed=False)),
+               (1, DICT, np.frombuffer(b"".join(dwords), dtype=np.uint8)),
+               (2, PRESENT, gen.boolean(present)), (2, DATA, gen.rle2(rng.integers(-10**9, 10**9, k), signed=True)),
+               (3, PRESENT, gen.boolean(present)), (3, LENGTH, gen.rle2(np.array([len(dwords[i]) for i in idx], dtype=np.int64), signed=False)),
+               (3, DATA, np.frombuffer(b"".join(dwords[i] for i in idx), dtype=np.uint8)),
+               (4, PRESENT, gen.boolean(present)), (4, DATA, gen.boolean((rng.random(k) < 0.5).astype(np.uint8)))]
+    res = G.gpu_decode(n, cols, streams, batch_size=batch)
+    for ci, c in enumerate(cols):
+        G.assert_column_parity(res, ci, c, streams, n, batch, what=("batch", batch, ci))
+    res.free()
+
+
 def test_strings_direct_and_dictionary():
     STRING, BINARY, LENGTH, DICT = 7, 8, 2, 3
     n = 30000
