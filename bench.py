@@ -105,11 +105,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # BENCH_BACKEND=gloo is a dry-run aid for boxes with fewer GPUs than ranks (ranks then share devices and
+    # the two tiny collectives run on CPU tensors); the driver's runs use the default, RCCL ("nccl").
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -161,11 +170,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # the path's only exchange: per-rank row counts (so every rank knows the global row offsets)
-        cnt = torch.tensor([rows], device="cuda", dtype=torch.int64)
+        cnt = torch.tensor([rows], device=coll_dev, dtype=torch.int64)
         allc = [torch.zeros_like(cnt) for _ in range(world)]
         dist.all_gather(allc, cnt)
         total_rows = int(sum(int(c.item()) for c in allc))
