@@ -143,6 +143,31 @@ __device__ const uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4,
 __device__ __forceinline__ int inflate_codes_dev(BitRd& b, LzOut& o, uint32_t cap, const HuffTab& lc, const HuffTab& dc,
                                                   uint32_t lane) {
   for (;;) {
+    // Literals, up to four per trip: four chained table lookups (a code of the fast table is at most 10
+    // bits), one 4-byte store into the ring by lane 0, one round of bookkeeping.  Anything else -- a
+    // long code, a length symbol, end of block -- leaves the trip to the one-symbol path below.
+    if (b.bc < 40) br_refill(b);
+    const uint32_t rpos = (uint32_t)o.out & o.rmask;
+    if (b.bc >= 40 && o.out + 4 <= cap && rpos + 4 <= o.rmask + 1) {
+      uint32_t acc = 0, k = 0, used = 0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const uint32_t e = lc.fast[(uint32_t)(b.bb >> used) & 1023];
+        if (e == 0 || (e & 0xfff) >= 256) break;
+        acc |= (e & 0xff) << (8 * k);
+        k++;
+        used += e >> 12;
+      }
+      if (k) {
+        if (lane == 0) __builtin_memcpy(o.ring + rpos, &acc, 4);  // bytes beyond k are overwritten by what follows
+        b.bb >>= used;
+        b.bc -= used;
+        o.out += k;
+        lz_maybe_flush(o, lane);
+        if (br_overrun(b)) return 1;
+        continue;
+      }
+    }
     int sym = huff_decode_dev(b, lc);
     if (sym < 0) return 1;
     if (sym < 256) {
