@@ -470,7 +470,12 @@ int oo_column_next_batch(oo_column* c, uint64_t batch_size, oo_batch* out) {
           c->offsets[i + 1] = (int32_t)acc;
         }
         extern int oo__reader_status(const oo_reader*);
-        if (got < (size_t)total) st = oo__reader_status(c->r_data) == OO_BUILD_DECODER ? OO_BUILD_DECODER : OO_ARROW; /* try_new: offsets past the values buffer */
+        if (got < (size_t)total) {
+          /* a stream cut short by its container (rejected block / broken framing) reports that; a stream that is
+           * simply too short is not an IoError for read_to_end -- try_new then rejects offsets past the buffer */
+          int rs = oo__reader_status(c->r_data);
+          st = rs ? rs : OO_ARROW;
+        }
         if (!st && t != OO_T_BINARY) {
           if (!utf8_valid(c->values, (size_t)total)) st = OO_ARROW;
           for (size_t i = 0; i <= n && !st; i++) {

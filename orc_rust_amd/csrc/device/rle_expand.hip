@@ -533,7 +533,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
     PROF_MARK(14);
   }
   // clean end of stream before `needed` values: "not enough values to decode"
-  if (tail_owner && clean && pos >= len) report(j, needed, oi, eof_code);
+  if (tail_owner && clean && pos >= len) report(j, needed, oi, eof_code | ORC_E_EOF);
 }
 
 template <int CODEC>

@@ -30,6 +30,9 @@
 #define ORC_E_OFFSET_OVERFLOW 5u
 #define ORC_E_ARROW 8u
 #define ORC_E_CODEC 9u
+// flag on a reported code: the error is "the stream ran dry" whatever its kind (ORC_E_IO always means that).  The host
+// turns such an error into the container's own one when the stream was cut short by a rejected / mis-framed chunk.
+#define ORC_E_EOF 0x40u
 
 enum : int { CODEC_RLE2 = 0, CODEC_RLE1 = 1, CODEC_BYTE = 2 };
 enum : int { RT_SR = 0, RT_DIRECT = 1, RT_PATCHED = 2, RT_DELTA = 3,   // RLE v2 sub-encodings
@@ -303,7 +306,14 @@ __device__ __forceinline__ void rle2_parse(const uint8_t* p, uint64_t avail, boo
           h.err = ORC_E_OUT_OF_SPEC;                                     // delta.rs:95 `length - 2` underflow
           h.size = h.payload;
         } else if (h.size > avail) {
+          // delta.rs:80-93 takes the first step base +/- |delta_base| (checked in N) before it reads the packed deltas
           h.err = ORC_E_IO;
+          const int64_t b0 = is_signed ? zigzag_n(ub, nbits) : trunc_n((int64_t)ub, nbits);
+          const int64_t db = zigzag_n(ud, 64);
+          const int64_t mag = db < 0 ? (int64_t)(0 - (uint64_t)db) : db;
+          const int64_t v1 = (int64_t)(db > 0 ? (uint64_t)b0 + (uint64_t)mag : (uint64_t)b0 - (uint64_t)mag);
+          const bool ovf = db > 0 ? ((b0 ^ v1) & (mag ^ v1)) < 0 : ((b0 ^ mag) & (b0 ^ v1)) < 0;
+          if (ovf || trunc_n(v1, nbits) != v1) h.err = ORC_E_OUT_OF_SPEC;
         }
         if (FULL) {
           h.base = is_signed ? zigzag_n(ub, nbits) : trunc_n((int64_t)ub, nbits);

@@ -13,12 +13,14 @@ __device__ __forceinline__ void report_err64(unsigned long long* err, uint64_t i
   atomicMin(err, ((unsigned long long)idx << 8) | code);
 }
 
-// ---- lengths / keys -> per-row int32 lengths ------------------------------------------------------
-// dense: int64 lengths (direct) or keys (dictionary) of the non-null rows.
-// dict_off == nullptr: direct strings.  rows with a negative length / key out of range raise Arrow.
+// ---- direct strings: decoded lengths -> per-row int32 lengths -----------------------------------------
+// dense: int64 lengths of the non-null rows.  GenericByteArrayDecoder::next_byte_batch (string.rs) first sums the
+// batch's lengths as they are (i64, negative ones included) and raises OffsetOverflow when the sum exceeds
+// i32::MAX; only then do negative lengths surface as an Arrow error.  A length outside 0..=i32::MAX is stored as 0
+// and added to the batch's correction term `corr[b]`, so that batch_offsets_kernel sees the exact signed sum.
 extern "C" __global__ void __launch_bounds__(256) string_lens_kernel(const int64_t* dense, const unsigned long long* vbits, const uint32_t* rank,
-                                                                      const int32_t* dict_off, const uint64_t* scalars, uint32_t dict_n_idx,
-                                                                      int32_t* lens, int32_t* keys, uint64_t n_rows, unsigned long long* err) {
+                                                                      int32_t* lens, uint64_t n_rows, uint32_t batch, unsigned long long* corr,
+                                                                      unsigned long long* err) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_rows) return;
   uint64_t d = i;
@@ -29,34 +31,25 @@ extern "C" __global__ void __launch_bounds__(256) string_lens_kernel(const int64
     valid = (word >> bit) & 1;
     d = (uint64_t)rank[i >> 6] + __builtin_popcountll(word & ((1ull << bit) - 1));
   }
-  int32_t len = 0, key = 0;
+  int32_t len = 0;
   if (valid) {
     int64_t v = dense[d];
-    if (dict_off) {
-      uint64_t dict_n = scalars[dict_n_idx];
-      if (v < 0 || (uint64_t)v >= dict_n) {
-        report_err64(err, i, ORC_E_ARROW);
-      } else {
-        key = (int32_t)v;
-        len = dict_off[v + 1] - dict_off[v];
-      }
-    } else {
+    if (v < 0 || v > 0x7fffffffll) {
+      atomicAdd(&corr[i / batch], (unsigned long long)v);
       if (v < 0) report_err64(err, i, ORC_E_ARROW);
-      else if (v > 0x7fffffffll) {
-        report_err64(err, i, ORC_E_OFFSET_OVERFLOW);
-      } else {
-        len = (int32_t)v;
-      }
+    } else {
+      len = (int32_t)v;
     }
   }
   lens[i] = len;
-  if (keys) keys[i] = key;
 }
 
 // ---- per-batch exclusive scan of the lengths -> offsets (restart at 0 per batch) -------------------
 // One workgroup per batch.  offsets layout: batch b at b * (batch + 1).
+// corr: per-batch sum of the lengths string_lens_kernel stored as 0 (see there).
 extern "C" __global__ void __launch_bounds__(256) batch_offsets_kernel(const int32_t* lens, uint64_t n_rows, uint32_t batch, int32_t* offsets,
-                                                                        unsigned long long* chartot, unsigned long long* err, uint32_t ovf_code) {
+                                                                        unsigned long long* chartot, const unsigned long long* corr,
+                                                                        unsigned long long* err, uint32_t ovf_code) {
   __shared__ uint64_t wsum[4];
   __shared__ uint64_t carry_s;
   uint64_t b = blockIdx.x;
@@ -85,7 +78,7 @@ extern "C" __global__ void __launch_bounds__(256) batch_offsets_kernel(const int
   if (threadIdx.x == 0) {
     out[rows] = (int32_t)carry_s;
     chartot[b] = carry_s;
-    if (carry_s > 0x7fffffffull) report_err64(err, row0, ovf_code);
+    if ((long long)(carry_s + corr[b]) > 0x7fffffffll) report_err64(err, row0, ovf_code);
   }
 }
 
@@ -129,6 +122,7 @@ struct DictJob {
   int32_t* keys;                    // workspace: key per row (0 for nulls)
   unsigned long long* chartot;      // per-batch byte totals, then (at + n_batches) their exclusive scan
   unsigned long long* err;
+  const unsigned long long* dict_err;  // error word of the dictionary itself (bad lengths / short blob): nothing of it may be touched then
   uint8_t* out_chars;               // value bytes of the column (set for the gather launch)
   uint64_t* total_out;              // scalar receiving the column's total value bytes
   uint64_t n_rows;
@@ -147,6 +141,7 @@ __device__ __forceinline__ DictJob dict_job(const DictJob* jobs, uint32_t i) {
   j.keys = glob(j.keys);
   j.chartot = glob(j.chartot);
   j.err = glob(j.err);
+  j.dict_err = glob(j.dict_err);
   j.out_chars = glob(j.out_chars);
   j.total_out = glob(j.total_out);
   return j;
@@ -165,7 +160,10 @@ extern "C" __global__ void __launch_bounds__(256) dict_rows_kernel(const DictJob
   const DictJob j = dict_job(jobs, blockIdx.y);
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   if (b >= j.n_batches) return;
-  const uint64_t dict_n = scalars[j.dict_n_idx];
+  // a dictionary that failed its own checks (negative / overflowing lengths, blob shorter than their sum) fails the
+  // column at construction; its offsets are not to be trusted: every row gets an empty string, nothing is gathered
+  const bool dict_ok = *j.dict_err == RLE_NO_ERR;
+  const uint64_t dict_n = dict_ok ? scalars[j.dict_n_idx] : 0;
   const bool cached = dict_n <= DICT_DOFF_LDS;
   if (cached)
     for (uint32_t i = tid; i <= dict_n; i += 256) doffc[i] = j.doff[i];
@@ -207,7 +205,9 @@ extern "C" __global__ void __launch_bounds__(256) dict_rows_kernel(const DictJob
         uint32_t len = 0;
         int32_t key = 0;
         if (valid) {
-          if (v[u] < 0 || (uint64_t)v[u] >= dict_n) {
+          if (!dict_ok) {
+            // (the dictionary error is what the column reports)
+          } else if (v[u] < 0 || (uint64_t)v[u] >= dict_n) {
             report_err64(j.err, i, ORC_E_ARROW);
           } else {
             key = (int32_t)v[u];
@@ -295,7 +295,7 @@ extern "C" __global__ void __launch_bounds__(256) dict_gather2_kernel(const Dict
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   if (b >= j.n_batches) return;
   const uint64_t total = j.chartot[b];
-  if (!total || !j.out_chars) return;
+  if (!total || !j.out_chars || *j.dict_err != RLE_NO_ERR) return;
   const uint64_t row0 = (uint64_t)b * j.batch;
   const uint32_t rows = (uint32_t)(j.n_rows - row0 < j.batch ? j.n_rows - row0 : j.batch);
   const int32_t* off = j.offsets + (uint64_t)b * ((uint64_t)j.batch + 1);
@@ -398,11 +398,12 @@ extern "C" __global__ void __launch_bounds__(256) dict_offsets_kernel(const int6
   if (threadIdx.x == 0) {
     uint64_t total = carry_s;
     dict_off[n] = (int32_t)(total > 0x7fffffffull ? 0x7fffffff : total);
-    *dict_bytes_out = total;
+    // (what the UTF-8 checks may look at: never more than the blob holds)
+    *dict_bytes_out = total < scalars[data_len_idx] ? total : scalars[data_len_idx];
     // construction errors fail the whole stripe decoder (new_string_decoder `?`, string.rs:70-72): index 0
     if (total > 0x7fffffffull) report_err64(err, 0, ORC_E_OFFSET_OVERFLOW);
     else if (bad_s) report_err64(err, 0, ORC_E_ARROW);
-    else if (total > scalars[data_len_idx]) report_err64(err, 0, ORC_E_ARROW);  // offsets past the values buffer (try_new)
+    else if (total > scalars[data_len_idx]) report_err64(err, 0, ORC_E_ARROW | ORC_E_EOF);  // offsets past the values buffer (try_new)
   }
 }
 
@@ -415,11 +416,11 @@ __device__ __forceinline__ int utf8_lead_len(uint8_t c) {
   if (c >= 0xf0 && c <= 0xf4) return 4;
   return 0;  // continuation (0x80..0xbf) or invalid (0xc0, 0xc1, 0xf5..0xff)
 }
-extern "C" __global__ void __launch_bounds__(256) utf8_validate_kernel(const uint8_t* s, const uint64_t* scalars, uint32_t n_idx, uint64_t n_upper,
+extern "C" __global__ void __launch_bounds__(256) utf8_validate_kernel(const uint8_t* s, const uint64_t* scalars, uint32_t n_idx, uint32_t len_idx,
                                                                         unsigned long long* err) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t n = scalars[n_idx];
-  if (n > n_upper) n = n_upper;
+  if (n > scalars[len_idx]) n = scalars[len_idx];  // only bytes the stream really holds (a cut stream leaves stale ones behind)
   if (i >= n) return;
   uint8_t c = s[i];
   if (c < 0x80) return;
@@ -452,17 +453,39 @@ extern "C" __global__ void __launch_bounds__(256) utf8_validate_kernel(const uin
   if (bad) report_err64(err, i, ORC_E_ARROW);
 }
 
-// Every row offset (and thereby every batch start) must sit on a character boundary.
-// base: per-batch byte base (nullptr for the dictionary: one "batch" with base 0 and stride n+1).
+// StringArray::try_new per batch: after the UTF-8 check of the batch's bytes, every row offset that lies INSIDE the
+// batch's bytes must sit on a character boundary (an empty row at the very end of the batch is not looked at).
+// The bytes of all batches sit back to back and utf8_validate_kernel checks them as one text, so one more case is
+// settled here: a batch that starts inside a character means the batch before it ends inside one -- that one is
+// invalid on its own and fails first.
+// charbase / chartot: per-batch byte base and size (nullptr for the dictionary: one "batch" of n_rows offsets).
+// Only bytes that exist are looked at (len_idx: the stream's real length); a batch that runs past them is reported
+// by string_data_check_kernel / dict_offsets_kernel.
 extern "C" __global__ void __launch_bounds__(256) utf8_boundaries_kernel(const uint8_t* s, const int32_t* offsets, const unsigned long long* charbase,
-                                                                          uint64_t n_rows, uint32_t batch, const uint64_t* scalars, uint32_t n_idx,
+                                                                          const unsigned long long* chartot, uint64_t n_rows, uint32_t batch,
+                                                                          const uint64_t* scalars, uint32_t n_idx, uint32_t len_idx,
                                                                           unsigned long long* err) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_rows) return;
-  uint64_t b = i / batch;
-  uint64_t p = (charbase ? charbase[b] : 0) + (uint64_t)(uint32_t)offsets[b * ((uint64_t)batch + 1) + (i - b * batch)];
+  const uint64_t b = i / batch;
+  const uint64_t base = charbase ? charbase[b] : 0;
+  const uint64_t p = base + (uint64_t)(uint32_t)offsets[b * ((uint64_t)batch + 1) + (i - b * batch)];
+  const uint64_t have = scalars[len_idx];
   uint64_t n = scalars[n_idx];
-  if (p < n && (s[p] & 0xc0) == 0x80) report_err64(err, i, ORC_E_ARROW);
+  if (n > have) n = have;
+  if (p >= n || (s[p] & 0xc0) != 0x80) return;
+  if (charbase && i > 0 && i == b * batch) {
+    // first row of a batch on a continuation byte that belongs to a character begun before it
+    for (int k = 1; k <= 3 && (uint64_t)k <= p; k++) {
+      uint8_t q = s[p - k];
+      if ((q & 0xc0) == 0x80) continue;
+      if (utf8_lead_len(q) > k) report_err64(err, i - 1, ORC_E_ARROW);
+      break;
+    }
+  }
+  const uint64_t end = chartot ? base + chartot[b] : n;
+  if (end > have) return;
+  if (p < end) report_err64(err, i, ORC_E_ARROW);
 }
 
 // Direct strings: the bytes consumed by all batches must exist in DATA (try_new: offsets past the buffer)
@@ -470,7 +493,7 @@ extern "C" __global__ void string_data_check_kernel(const unsigned long long* ch
                                                     const uint64_t* scalars, uint32_t data_len_idx, uint32_t batch, unsigned long long* err) {
   uint32_t b = blockIdx.x * 64 + threadIdx.x;
   if (b >= n_batches) return;
-  if (charbase[b] + chartot[b] > scalars[data_len_idx]) report_err64(err, (uint64_t)b * batch, ORC_E_ARROW);
+  if (charbase[b] + chartot[b] > scalars[data_len_idx]) report_err64(err, (uint64_t)b * batch, ORC_E_ARROW | ORC_E_EOF);
 }
 
 // ---- Decimal: zigzag varints -> i128 ----------------------------------------------------------------
