@@ -92,8 +92,16 @@ __device__ __forceinline__ bool add_ovf(int64_t a, int64_t b, int64_t r) { retur
 // a - b == r (wrapping): did the signed subtraction overflow?
 __device__ __forceinline__ bool sub_ovf(int64_t a, int64_t b, int64_t r) { return ((a ^ b) & (a ^ r)) < 0; }
 
-__device__ __forceinline__ void report(RleJob* j, uint64_t needed, uint64_t oi, uint32_t code) {
-  if (oi < needed) atomicMin(&j->err, ((unsigned long long)oi << 8) | code);
+// The reference stops at the first failing run.  Here every wavefront reports what it meets, speculative runs behind
+// a failure included, and two minima pick the first one out: it has the smallest value index (err) -- though runs
+// behind a run that failed to parse share that index, since such a run yields no values -- and the smallest stream
+// position (err_pos), which settles the error kind.  `pos`: the run's first byte for a run that fails to parse, the
+// last byte of its header (payload - 1: a fixed DELTA run's payload is already the next run) for one that fails later.
+__device__ __forceinline__ void report(RleJob* j, uint64_t needed, uint64_t oi, uint32_t code, uint64_t pos) {
+  if (oi < needed) {
+    atomicMin(&j->err, ((unsigned long long)oi << 8) | code);
+    atomicMin(&j->err_pos, ((unsigned long long)pos << 8) | code);
+  }
 }
 
 // One value of a random-access run (SHORT_REPEAT, DIRECT, fixed DELTA, v1 run, byte run / literal).
@@ -215,7 +223,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
         active = clean && pos < end && oi < needed;
       }
       if (h.err) {
-        report(j, needed, soi, h.err);
+        report(j, needed, soi, h.err, sp);
       } else {
         is_b2 = (h.type == RT_DELTA && h.width != 0) || h.type == RT_PATCHED || h.type == RT_V1_LIT;
         cnt = is_b2 ? 0 : h.n;
@@ -260,7 +268,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
             uint64_t oo = o0 + i0 + u * 64 + lane;
             if (oo < needed) store_val(out, ob, oo, v[u]);
           }
-          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
+          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[cur] - 1);
           q0 += 512;
           continue;
         }
@@ -318,7 +326,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
             int64_t pr[2] = {va[u], vb[u]};
             __builtin_memcpy((int64_t*)out + o0 + i0 + u * 128 + 2 * lane, pr, 16);
           }
-          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
+          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[cur] - 1);
           q0 += 512;
           continue;
         }
@@ -339,7 +347,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
             uint64_t oo = o0 + i0 + u * 64 + lane;
             if (oo < needed) store_val(out, ob, oo, v[u]);
           }
-          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
+          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[cur] - 1);
           q0 += 256;
           continue;
         }
@@ -360,7 +368,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           uint64_t o0 = L.oidx[r];
           bool bad = false;
           int64_t v = decode_b1(m & 0xff, (m >> 8) & 0xff, L.base[r], L.delta[r], data + L.pay[r], idx, is_signed, nbits, bad);
-          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
+          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[r] - 1);
           uint64_t oo = o0 + idx;
           if (oo < needed) store_val(out, ob, oo, v);
         }
@@ -526,14 +534,14 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
         }
       }
       if (__ballot(bad)) {
-        if (lane == 0) report(j, needed, o0, ORC_E_OUT_OF_SPEC);
+        if (lane == 0) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[r] - 1);
       }
     }
     wave_sync();
     PROF_MARK(14);
   }
   // clean end of stream before `needed` values: "not enough values to decode"
-  if (tail_owner && clean && pos >= len) report(j, needed, oi, eof_code | ORC_E_EOF);
+  if (tail_owner && clean && pos >= len) report(j, needed, oi, eof_code | ORC_E_EOF, len);
 }
 
 template <int CODEC>

@@ -29,6 +29,7 @@ struct RleJob {
   uint32_t stat_bad;       // verify round: number of inconsistent blocks (diagnostics)
   uint32_t stat_repaired;  // repair kernel: blocks rewritten (diagnostics)
   unsigned long long err;  // min over (first value index of the failing run << 8 | ORC_E_*)
+  unsigned long long err_pos;  // min over (stream position of the failing run << 8 | ORC_E_*): its code is the first failure's
 };
 
 struct RleBlocks {

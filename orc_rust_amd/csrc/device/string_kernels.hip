@@ -36,7 +36,9 @@ extern "C" __global__ void __launch_bounds__(256) string_lens_kernel(const int64
     int64_t v = dense[d];
     if (v < 0 || v > 0x7fffffffll) {
       atomicAdd(&corr[i / batch], (unsigned long long)v);
-      if (v < 0) report_err64(err, i, ORC_E_ARROW);
+      // (reported at the batch's first row, where the batch-level checks report too: the lower code wins a tie, which is
+      //  the reference's order -- OffsetOverflow, negative length, values past the DATA stream)
+      if (v < 0) report_err64(err, i / batch * batch, ORC_E_ARROW);
     } else {
       len = (int32_t)v;
     }

@@ -32,8 +32,9 @@ def ints(rng, k, bits):
     return np.asarray(v, dtype=np.int64)
 
 
-def make_case(seed, corrupt):
-    """-> (n_rows, compression, block_size, batch_size, columns, streams, corrupted (column, kind) or None)"""
+def make_case(seed, corrupt, hits=1):
+    """-> (n_rows, compression, block_size, batch_size, columns, streams, corrupted (column, kind) or None)
+    hits > 1: that many more (stream, byte) pairs are overwritten, drawn from a second generator."""
     rng = np.random.default_rng(seed)
     n = int(rng.choice([1, 17, 511, 512, 513, 4097, 20000, 70001]))
     comp = str(rng.choice(["none", "none", "snappy", "lz4", "zlib", "zstd"]))
@@ -90,6 +91,15 @@ def make_case(seed, corrupt):
         if len(data_):
             data_[int(rng.integers(0, len(data_)))] = int(rng.integers(0, 256))
             streams[si] = (cid_, kind_, data_)
+    if corrupt and streams and hits > 1:
+        rng2 = np.random.default_rng(seed ^ 0x5EED)
+        for _ in range(hits - 1):
+            sj = int(rng2.integers(0, len(streams)))
+            cid_, kind_, data_ = streams[sj]
+            data_ = np.array(data_, dtype=np.uint8, copy=True)
+            if len(data_):
+                data_[int(rng2.integers(0, len(data_)))] = int(rng2.integers(0, 256))
+                streams[sj] = (cid_, kind_, data_)
     return n, comp, block, batch, cols, streams, ((streams[si][0], streams[si][1]) if corrupt and streams else None)
 
 
