@@ -400,12 +400,13 @@ extern "C" __global__ void __launch_bounds__(256) dict_offsets_kernel(const int6
   if (threadIdx.x == 0) {
     uint64_t total = carry_s;
     dict_off[n] = (int32_t)(total > 0x7fffffffull ? 0x7fffffff : total);
-    // (what the UTF-8 checks may look at: never more than the blob holds)
-    *dict_bytes_out = total < scalars[data_len_idx] ? total : scalars[data_len_idx];
     // construction errors fail the whole stripe decoder (new_string_decoder `?`, string.rs:70-72): index 0
+    const bool failed = total > 0x7fffffffull || bad_s || total > scalars[data_len_idx];
     if (total > 0x7fffffffull) report_err64(err, 0, ORC_E_OFFSET_OVERFLOW);
     else if (bad_s) report_err64(err, 0, ORC_E_ARROW);
     else if (total > scalars[data_len_idx]) report_err64(err, 0, ORC_E_ARROW | ORC_E_EOF);  // offsets past the values buffer (try_new)
+    // what the UTF-8 checks look at: nothing when the dictionary failed already (they come last in try_new)
+    *dict_bytes_out = failed ? 0 : total;
   }
 }
 

@@ -68,3 +68,43 @@ def assert_column_parity(res, ci, col, streams, n_rows, batch_size, compression=
         left -= n
         b += 1
     oc.close()
+
+
+def assert_stripe_parity(res, cols, streams, n_rows, batch_size, compression="none", block_size=262144, what=""):
+    """Stripe-level view for input on which several columns may fail: the reader ends at the first failing batch,
+    and inside it at the first failing column (arrow_reader.rs:333-346 decodes a batch column by column).  The GPU
+    result must name that (batch, column, kind), and agree bit for bit on every batch before it."""
+    nb = (n_rows + batch_size - 1) // batch_size
+    first = None  # (batch, column, status)
+    for ci, cc in enumerate(cols):
+        oc = oracle_column(cc, streams, compression, block_size)
+        if oc.status != O.OK:
+            first = min(first or (1 << 60, 0, 0), (0, ci, oc.status))
+            continue
+        left, b = n_rows, 0
+        while left > 0:
+            ob = oc.next_batch(min(batch_size, left))
+            if ob["status"] != O.OK:
+                first = min(first or (1 << 60, 0, 0), (b, ci, ob["status"]))
+                break
+            left -= batch_size
+            b += 1
+        oc.close()
+    gst, gb, gc = res.status()
+    if first is None:
+        assert gst == 0, (what, "gpu fails, oracle does not", gst, gb, gc)
+    else:
+        assert (gb, gc, gst) == first, (what, "first failure (batch, column, kind): gpu", (gb, gc, gst), "oracle", first)
+    for ci, cc in enumerate(cols):
+        oc = oracle_column(cc, streams, compression, block_size)
+        left = n_rows
+        for b in range(nb if first is None else first[0]):
+            ob = oc.next_batch(min(batch_size, left))
+            left -= batch_size
+            assert ob["status"] == O.OK
+            g = res.batch(b, ci)
+            assert g["null_count"] == ob["null_count"] and g["validity"] == ob["validity"], (what, "validity", ci, b)
+            assert g["values"] == ob["values"], (what, "values", ci, b)
+            if ob["offsets"] is not None:
+                assert np.array_equal(g["offsets"], ob["offsets"]), (what, "offsets", ci, b)
+        oc.close()

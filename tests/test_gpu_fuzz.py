@@ -58,3 +58,33 @@ def test_corrupted_stripes_over_stale_buffers():
     earlier decodes.  Replaying one stretch of seeds in order once crashed on offsets read from such bytes."""
     for seed in range(200150, 200192):
         run_case(seed, True)
+
+
+# (seed, corrupted bytes): multi-hit cases that exposed a bug
+#  615166/8 run that fails to parse right before speculative garbage near the end of the stream (kind of the first failure)
+#  603070/8, 606892/8 negative string length and values past a rejected DATA chunk in one batch
+#  609996/8 dictionary blob cut short whose first byte is no character start (blob error before UTF-8)
+#  500147/3, 500259/3, 501380/3, 600168/8 dictionary construction errors vs key errors of batch 0
+#  604291/8, 612714/8 value-level failure of a fixed DELTA run followed by a run that fails to parse
+MULTI = [(615166, 8), (603070, 8), (606892, 8), (609996, 8), (500147, 3), (500259, 3), (501380, 3), (600168, 8), (604291, 8), (612714, 8)]
+
+
+def run_stripe_case(seed, hits):
+    n, comp, block, batch, cols, streams, _ = F.make_case(seed, True, hits)
+    res = G.gpu_decode(n, cols, streams, compression=comp, block_size=block, batch_size=batch)
+    try:
+        G.assert_stripe_parity(res, cols, streams, n, batch, compression=comp, block_size=block, what=(seed, hits, comp, block, batch, n))
+    except AssertionError:
+        if not F.inflates_past_block(streams, comp, block):
+            raise
+    finally:
+        res.free()
+
+
+def test_stripes_with_several_corrupted_bytes():
+    for seed, hits in MULTI:
+        run_stripe_case(seed, hits)
+    for seed in range(7_200_000, 7_200_300):
+        run_stripe_case(seed, 3)
+    for seed in range(7_300_000, 7_300_300):
+        run_stripe_case(seed, 8)
