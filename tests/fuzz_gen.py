@@ -91,6 +91,14 @@ def make_case(seed, corrupt, hits=1):
         if len(data_):
             data_[int(rng.integers(0, len(data_)))] = int(rng.integers(0, 256))
             streams[si] = (cid_, kind_, data_)
+    if corrupt and streams and hits < 0:
+        # hits < 0: additionally cut -hits random streams short at a random length
+        rng2 = np.random.default_rng(seed ^ 0xC07)
+        for _ in range(-hits):
+            sj = int(rng2.integers(0, len(streams)))
+            cid_, kind_, data_ = streams[sj]
+            data_ = np.array(data_, dtype=np.uint8, copy=True)
+            streams[sj] = (cid_, kind_, data_[:int(rng2.integers(0, len(data_) + 1))].copy())
     if corrupt and streams and hits > 1:
         rng2 = np.random.default_rng(seed ^ 0x5EED)
         for _ in range(hits - 1):

@@ -88,3 +88,25 @@ def test_stripes_with_several_corrupted_bytes():
         run_stripe_case(seed, 3)
     for seed in range(7_300_000, 7_300_300):
         run_stripe_case(seed, 8)
+    for seed in range(7_400_000, 7_400_300):
+        run_stripe_case(seed, -2)  # one overwritten byte and two streams cut short
+
+
+def test_failing_stripes_do_not_disturb_their_neighbours():
+    """Stripes of one orcgpu_decode_staged call share every launch (one job table, one summary): valid and
+    corrupted stripes mixed in one call must each come out as they do alone."""
+    ctx = G.ctx()
+    for base in range(7_500_000, 7_500_120, 12):
+        cases = [F.make_case(base + k, k % 3 == 1, 3) for k in range(12)]
+        staged = [ctx.stage(n, streams, cols, compression=comp, block_size=block, batch_size=batch) for n, comp, block, batch, cols, streams, _ in cases]
+        results = ctx.decode(staged)
+        for (n, comp, block, batch, cols, streams, _), res in zip(cases, results):
+            try:
+                G.assert_stripe_parity(res, cols, streams, n, batch, compression=comp, block_size=block, what=(base, comp, block, batch, n))
+            except AssertionError:
+                if not F.inflates_past_block(streams, comp, block):
+                    raise
+        for r in results:
+            r.free()
+        for s in staged:
+            s.free()
