@@ -80,7 +80,10 @@ extern "C" __global__ void __launch_bounds__(256) batch_offsets_kernel(const int
   if (threadIdx.x == 0) {
     out[rows] = (int32_t)carry_s;
     chartot[b] = carry_s;
-    if ((long long)(carry_s + corr[b]) > 0x7fffffffll) report_err64(err, row0, ovf_code);
+    const long long total = (long long)(carry_s + corr[b]);  // i64 sum as the reference forms it (wrapping)
+    if (total > 0x7fffffffll) report_err64(err, row0, ovf_code);
+    // huge lengths that wrap the sum below zero: `total as usize` bytes are then asked of DATA, which runs dry
+    else if (total < 0) report_err64(err, row0, ORC_E_ARROW | ORC_E_EOF);
   }
 }
 

@@ -5,6 +5,7 @@ import numpy as np
 from orc_rust_amd import gen
 
 LONG, INT, SHORT, DATE, BYTE, BOOLEAN, FLOAT, DOUBLE, TIMESTAMP, STRING, BINARY, DECIMAL = 4, 3, 2, 15, 1, 0, 5, 6, 9, 7, 8, 14
+VARCHAR, CHAR, TIMESTAMP_INSTANT = 16, 17, 18
 PRESENT, DATA, LENGTH, DICT, SECONDARY = 0, 1, 2, 3, 5
 
 
@@ -32,9 +33,11 @@ def ints(rng, k, bits):
     return np.asarray(v, dtype=np.int64)
 
 
-def make_case(seed, corrupt, hits=1):
+def make_case(seed, corrupt, hits=1, wide=False):
     """-> (n_rows, compression, block_size, batch_size, columns, streams, corrupted (column, kind) or None)
-    hits > 1: that many more (stream, byte) pairs are overwritten, drawn from a second generator."""
+    hits > 1: that many more (stream, byte) pairs are overwritten, drawn from a second generator.
+    wide: also Binary / Varchar / Char / TimestampInstant columns and decimals of other precisions and scales
+    (a separate family of cases: the draws differ from the wide=False ones of the same seed)."""
     rng = np.random.default_rng(seed)
     n = int(rng.choice([1, 17, 511, 512, 513, 4097, 20000, 70001]))
     comp = str(rng.choice(["none", "none", "snappy", "lz4", "zlib", "zstd"]))
@@ -47,7 +50,10 @@ def make_case(seed, corrupt, hits=1):
     ncols = int(rng.integers(1, 5))
     for ci in range(ncols):
         cid = ci + 1
-        typ = int(rng.choice([LONG, INT, SHORT, DATE, BYTE, BOOLEAN, DOUBLE, FLOAT, TIMESTAMP, STRING, DECIMAL]))
+        kinds = [LONG, INT, SHORT, DATE, BYTE, BOOLEAN, DOUBLE, FLOAT, TIMESTAMP, STRING, DECIMAL]
+        if wide:
+            kinds += [BINARY, BINARY, VARCHAR, CHAR, TIMESTAMP_INSTANT, DECIMAL]
+        typ = int(rng.choice(kinds))
         nullf = float(rng.choice([0.0, 0.0, 0.1, 0.5, 0.95]))
         has_p = nullf > 0 or rng.random() < 0.2
         present = (rng.random(n) >= nullf).astype(np.uint8)
@@ -67,13 +73,13 @@ def make_case(seed, corrupt, hits=1):
             cols.append(dict(column_id=cid, orc_type=typ, encoding=0)); streams.append((cid, DATA, c(rng.standard_normal(k).view(np.uint8))))
         elif typ == FLOAT:
             cols.append(dict(column_id=cid, orc_type=typ, encoding=0)); streams.append((cid, DATA, c(rng.standard_normal(k).astype(np.float32).view(np.uint8))))
-        elif typ == TIMESTAMP:
+        elif typ in (TIMESTAMP, TIMESTAMP_INSTANT):
             secs = rng.integers(-2_000_000_000, 2_000_000_000, k); nanos = rng.integers(0, 1_000_000, k) * 1000
             cols.append(dict(column_id=cid, orc_type=typ, encoding=enc))
             streams.append((cid, DATA, c(rle(secs, True)))); streams.append((cid, SECONDARY, c(rle(np.where(nanos == 0, 0, (nanos // 1000 << 3) | 2), False))))
-        elif typ == STRING:
+        elif typ in (STRING, BINARY, VARCHAR, CHAR):
             words = [b"AIR", b"FOB", b"MAIL", b"RAIL", b"REG AIR", b"SHIP", b"TRUCK", b"", "héllo".encode(), b"x" * 70]
-            if rng.random() < 0.5:
+            if typ != BINARY and rng.random() < 0.5:
                 cols.append(dict(column_id=cid, orc_type=typ, encoding=3 if v2 else 1, dictionary_size=len(words)))
                 streams += [(cid, DATA, c(rle(rng.integers(0, len(words), k), False))), (cid, LENGTH, c(rle(np.array([len(w) for w in words], dtype=np.int64), False))),
                             (cid, DICT, c(np.frombuffer(b"".join(words), dtype=np.uint8)))]
@@ -82,7 +88,8 @@ def make_case(seed, corrupt, hits=1):
                 cols.append(dict(column_id=cid, orc_type=typ, encoding=enc))
                 streams += [(cid, LENGTH, c(rle(np.array([len(words[i]) for i in idx], dtype=np.int64), False))), (cid, DATA, c(np.frombuffer(b"".join(words[i] for i in idx), dtype=np.uint8)))]
         else:
-            cols.append(dict(column_id=cid, orc_type=typ, encoding=enc, precision=38, scale=3))
+            prec, scale = (38, 3) if not wide else (int(rng.choice([5, 18, 19, 38])), int(rng.choice([0, 2, 3, 5])))
+            cols.append(dict(column_id=cid, orc_type=typ, encoding=enc, precision=prec, scale=scale))
             streams += [(cid, DATA, c(gen.varint128([int(x) for x in rng.integers(-10**15, 10**15, k)]))), (cid, SECONDARY, c(rle(rng.integers(0, 6, k), True)))]
     if corrupt and streams:
         si = int(rng.integers(0, len(streams)))

@@ -92,6 +92,26 @@ def test_stripes_with_several_corrupted_bytes():
         run_stripe_case(seed, -2)  # one overwritten byte and two streams cut short
 
 
+def test_wide_type_family():
+    """Binary / Varchar / Char / TimestampInstant columns, decimals of other precisions and scales."""
+    for seed in range(7_600_000, 7_600_250):
+        n, comp, block, batch, cols, streams, _ = F.make_case(seed, False, 1, True)
+        res = G.gpu_decode(n, cols, streams, compression=comp, block_size=block, batch_size=batch)
+        G.assert_stripe_parity(res, cols, streams, n, batch, compression=comp, block_size=block, what=(seed, comp, block, batch, n))
+        res.free()
+    # 3309319/4: string lengths whose i64 sum wraps below zero
+    for seed, hits in [(3309319, 4)] + [(s, 1 + s % 4) for s in range(7_700_000, 7_700_300)]:
+        n, comp, block, batch, cols, streams, _ = F.make_case(seed, True, hits, True)
+        res = G.gpu_decode(n, cols, streams, compression=comp, block_size=block, batch_size=batch)
+        try:
+            G.assert_stripe_parity(res, cols, streams, n, batch, compression=comp, block_size=block, what=(seed, hits, comp, block, batch, n))
+        except AssertionError:
+            if not F.inflates_past_block(streams, comp, block):
+                raise
+        finally:
+            res.free()
+
+
 def test_failing_stripes_do_not_disturb_their_neighbours():
     """Stripes of one orcgpu_decode_staged call share every launch (one job table, one summary): valid and
     corrupted stripes mixed in one call must each come out as they do alone."""
