@@ -33,13 +33,15 @@ def ints(rng, k, bits):
     return np.asarray(v, dtype=np.int64)
 
 
-def make_case(seed, corrupt, hits=1, wide=False):
+def make_case(seed, corrupt, hits=1, wide=False, rows=None):
     """-> (n_rows, compression, block_size, batch_size, columns, streams, corrupted (column, kind) or None)
     hits > 1: that many more (stream, byte) pairs are overwritten, drawn from a second generator.
     wide: also Binary / Varchar / Char / TimestampInstant columns and decimals of other precisions and scales
     (a separate family of cases: the draws differ from the wide=False ones of the same seed)."""
     rng = np.random.default_rng(seed)
     n = int(rng.choice([1, 17, 511, 512, 513, 4097, 20000, 70001]))
+    if rows is not None:
+        n = int(rows)  # big stripes: many scan tiles / expansion groups per stream
     comp = str(rng.choice(["none", "none", "snappy", "lz4", "zlib", "zstd"]))
     block = int(rng.choice([64, 1000, 4096, 262144]))
     batch = int(rng.choice([1, 100, 1024, 8192, 10000]))
