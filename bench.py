@@ -1,23 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- decoded GB/s + Mrows/s into Arrow for the ORC stripe decode hot path.
 
-Workload (BASELINE.json configs[1], "C2"): one RLEv2 Int64 column, 100 M rows, uncompressed,
-12 stripes of 8 388 608 rows (the last one shorter), seeded synthetic data:
-  * even stripes  DIRECT:  splitmix64(seed=1) & (2^40-1)  -> zigzag 41 bits -> aligned width 48,
-                           512-value runs (3074 B in -> 4096 B out per run)
-  * odd stripes   DELTA:   strictly increasing, deltas uniform in [1, 255] (seed=2) -> 8-bit
-                           varying-delta runs of 512 values
-i.e. the 50/50 DIRECT/DELTA mix of BASELINE.md.  A "step" decodes all stripes of the column
-once: staged stream bytes are already resident in HBM, Arrow buffers are left in HBM.
+Default workload = the one BASELINE.json's metric is quoted on, config C4 at single-GPU size: the stripes of a
+TPC-H-shaped `lineitem` table at scale factor 1 (6 001 215 rows, the 16 columns of the reference's
+scripts/convert_tpch.py:46-63: 3 x Int64, Int32, 4 x Decimal128(15,2), 3 x Date32, 4 dictionary Utf8, 1 direct
+Utf8), Zstandard level 3 in 256 KiB chunks, stripes of 2 189 312 rows (what the ORC C++ writer cuts at
+stripe_size = 64 MiB for this table), seeded synthetic data (orc_rust_amd/gen/tpchgen.c: no dbgen in the image).
+A "step" decodes every stripe once: compressed stream bytes are already resident in HBM (staged through the C ABI
+before the timed region), Arrow buffers are left in HBM.
 
-    python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--workload lineitem|c2|c2-direct|c2-delta|c2-arange|c3|c5]
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-Prints ONE JSON line (rank 0).  `value` = whole-job decoded GB/s (Arrow bytes out / time).
-`roofline` prices the dominant kernel (rle2_expand_kernel) with HIP events on the decoder's own
-stream; `cpu_baseline` is the CPU oracle (a port of the reference's algorithm, single thread)
-on the same streams on this box's host cores.  Multi-GPU: stripes are independent, every rank
-decodes its own copy of the workload (weak scaling), the only collective is the final RCCL
-all-gather of per-rank row counts.
+Prints ONE JSON line (rank 0).  `value` = whole-job decoded GB/s (Arrow bytes out of all ranks / time of the slowest
+rank).  `roofline` prices the dominant phase of the pipeline (HIP events on the decoder's own stream, per phase:
+orcgpu_last_phase_ms) against the HBM peak with the ALGORITHMIC bytes of SURVEY 8(d): staged stream bytes in + Arrow
+bytes out.  `cpu_baseline` = the CPU oracle (a C port of the reference's algorithm; the Rust reference cannot be
+built here) on a bounded sample of the same stripes on this box's host cores, 1 thread and all cores.
+
+Multi-GPU (`--gpus N`): the path shards with no data-path collective.  lineitem: COLUMN shard -- the 16 columns are
+spread over the ranks balanced by their Arrow bytes (orc_rust_amd.shard.column_shard), every rank stages and decodes
+only its own columns of every stripe; c2 / c5: STRIPE shard (round robin).  The total work is fixed ("strong"
+scaling).  The only exchange is one all-gather (RCCL) of {rows, value bytes of the rank's string columns, Arrow
+bytes, error word}; rank 0 checks that every column was decoded exactly once and that the row counts agree.
 """
 import argparse
 import json
@@ -30,63 +35,141 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ROWS_TOTAL = 100_000_000
-STRIPE_ROWS = 8_388_608
-HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+C2_ROWS, C2_STRIPE_ROWS = 100_000_000, 8_388_608
+PHASE_KERNELS = {
+    "decompress": "decompress_{lz,deflate,zstd}_kernel (block decompression of every chunk of the call)",
+    "walk": "rle_walk_kernel / rle_walk_short_kernel rounds + scans (run boundaries)",
+    "present": "pres_*_kernel (PRESENT -> validity, ranks)",
+    "expand": "rle2_expand_kernel (+ rle1 / byte expand)",
+    "finish": "finishers: null spacing, strings, varint / decimal, timestamps",
+}
 
 
-def build_workload(rows_total, stripe_rows, kind="mix"):
-    from orc_rust_amd import gen
+def build_workload(args, rank, world):
+    """Returns (stripes, compression, label, shard description).  stripes: [(n_rows, cols, streams, expect)] of THIS rank."""
+    from orc_rust_amd import shard
+    from orc_rust_amd.gen import workloads as W
+    wl = args.workload
+    if wl == "lineitem":
+        rows = args.rows or W.LINEITEM_SF1_ROWS
+        column_ids = None
+        desc = "all 16 columns"
+        if world > 1:
+            parts = shard.column_shard(W.LINEITEM_ARROW_BYTES_PER_ROW, world)
+            column_ids = [i + 1 for i in parts[rank]]
+            desc = "column shard x%d (LPT by Arrow bytes)" % world
+        stripes = W.lineitem_stripes(rows, W.LINEITEM_STRIPE_ROWS, args.compression or "zstd", column_ids=column_ids) if column_ids != [] else []
+        comp = args.compression or "zstd"
+        label = ("C4: TPC-H-shaped lineitem stripes, SF1-sized (%d rows, 16 columns: 3 Int64, Int32, 4 Decimal128(15,2), 3 Date32, "
+                 "4 dictionary Utf8, 1 direct Utf8), %s, %d-row stripes" % (rows, comp, W.LINEITEM_STRIPE_ROWS))
+        return [s[:4] for s in stripes], comp, label, desc
+    rows = args.rows or C2_ROWS
+    n_stripes = (rows + C2_STRIPE_ROWS - 1) // C2_STRIPE_ROWS
+    mine = shard.stripe_shard(n_stripes, rank, world)
+    desc = "all stripes" if world == 1 else "stripe shard x%d (round robin)" % world
     stripes = []
-    base = 0
-    s = 0
-    row = 0
-    while row < rows_total:
-        n = min(stripe_rows, rows_total - row)
-        if (kind == "mix" and s % 2 == 0) or kind == "direct":
-            vals = (gen.splitmix64(1 + s, n) & np.uint64((1 << 40) - 1)).astype(np.int64)
-            skind = "direct"
-        elif kind == "arange":
-            vals = np.arange(row, row + n, dtype=np.int64)
-            skind = "delta-fixed"
-        else:
-            deltas = (gen.splitmix64(2 + s, n) % np.uint64(255)).astype(np.int64) + 1
-            vals = np.cumsum(deltas) + base
-            skind = "delta"
-        stream, stats = gen.rle2(vals, signed=True, aligned=True, stats=True)
-        stripes.append({"n": n, "stream": stream, "kind": skind, "stats": stats, "first": vals[:4].copy(), "last": int(vals[-1]),
-                        "xor": int(np.bitwise_xor.reduce(vals.view(np.uint64))), "sum": int(vals.view(np.uint64).sum(dtype=np.uint64))})
-        row += n
-        s += 1
-    return stripes
+    if wl.startswith("c2"):
+        comp = "none"
+        base = 0
+        for s in range(n_stripes):
+            n = min(C2_STRIPE_ROWS, rows - s * C2_STRIPE_ROWS)
+            kind = {"c2": "direct" if s % 2 == 0 else "delta", "c2-direct": "direct", "c2-delta": "delta", "c2-arange": "arange"}[wl]
+            if s in mine:
+                stripes.append(W.c2_stripe(n, s, kind, row0=s * C2_STRIPE_ROWS)[:4])
+        label = "C2%s: RLEv2 Int64 column, %d rows, uncompressed, %d stripes" % (
+            " (DIRECT 48-bit / DELTA 8-bit alternating)" if wl == "c2" else " variant " + wl[3:], rows, n_stripes)
+    elif wl == "c3":
+        comp = args.compression or "snappy"
+        for s in mine:
+            stripes.append(W.c3_stripe(min(C2_STRIPE_ROWS, rows - s * C2_STRIPE_ROWS), s, comp))
+        label = "C3: dictionary Utf8 (7 entries) + PRESENT (10 %% nulls), %d rows, %s, %d stripes" % (rows, comp, n_stripes)
+    elif wl == "c5":
+        comp = args.compression or "lz4"
+        for s in mine:
+            stripes.append(W.c5_stripe(min(C2_STRIPE_ROWS, rows - s * C2_STRIPE_ROWS), s, comp)[:4])
+        label = "C5: Timestamp(ns), PATCHED_BASE seconds + DIRECT nanoseconds, %d rows, %s, %d stripes" % (rows, comp, n_stripes)
+    else:
+        raise SystemExit("unknown workload " + wl)
+    return stripes, comp, label, desc
 
 
-def cpu_baseline(stripes, budget_s=20.0):
-    """CPU oracle (oracle/: port of the reference's decoders, 1 thread) on a bounded sample."""
+_TASKS = []  # (n_rows, column, {kind: bytes}, compression): filled before the worker processes are forked
+
+
+def _oracle_stripe(index):
+    """Decodes one (stripe, column) with the CPU oracle, batch by batch; returns (rows, arrow bytes)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    rows = 0
-    arrow_bytes = 0
+    n, col, sd, comp = _TASKS[index]
+    oc = O.Column(col["orc_type"], col.get("encoding", 2), sd, dictionary_size=col.get("dictionary_size", 0), precision=col.get("precision", 0),
+                  scale=col.get("scale", 0), compression=comp)
+    assert oc.status == 0
+    left, out = n, 0
+    while left > 0:
+        b = oc.next_batch(min(8192, left))
+        assert b["status"] == 0
+        out += len(b["values"]) + (4 * (b["length"] + 1) if b["offsets"] is not None else 0) + (len(b["validity"]) if b["validity"] else 0)
+        left -= 8192
+    oc.close()
+    return n, out
+
+
+def cpu_baseline(stripes, comp, budget_s=12.0):
+    """CPU oracle (oracle/: C port of the reference's decoders -- the Rust reference cannot be built in this image) on
+    the host cores of this box: 1 thread (the reference decodes columns, batches and stripes sequentially) and all
+    cores (one task per (stripe, column)), each on a bounded sample of the same stripes."""
+    import multiprocessing as mp
+    tasks = _TASKS
+    del tasks[:]
+    for n, cols, streams, _ in stripes:
+        for c in cols:
+            sd = {k: (b.tobytes() if isinstance(b, np.ndarray) else bytes(b)) for cid, k, b in streams if cid == c["column_id"]}
+            tasks.append((n, {k: v for k, v in c.items()}, sd, comp))
+    ncols = max(1, len(stripes[0][1]))
+    # 1 thread: whole columns of the first stripe(s) until the budget is used
     t0 = time.perf_counter()
-    used = 0
-    for st in stripes:
-        col = O.Column(4, 2, {1: st["stream"].tobytes()})
-        left = st["n"]
-        while left > 0:
-            n = min(8192, left)
-            b = col.next_batch(n)
-            assert b["status"] == 0
-            left -= n
-        col.close()
-        rows += st["n"]
-        arrow_bytes += st["n"] * 8
+    rows1 = bytes1 = used = 0
+    for t in range(len(tasks)):
+        n, ab = _oracle_stripe(t)
+        bytes1 += ab
         used += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": round(arrow_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-            "mrows_per_s": round(rows / dt / 1e6, 2),
-            "sample": "%d of %d stripes (%d rows) of the same workload, batch 8192, oracle/liborc_oracle.so" % (used, len(stripes), rows)}
+        if used % ncols == 0:
+            rows1 += n
+            if time.perf_counter() - t0 > budget_s:
+                break
+    dt1 = time.perf_counter() - t0
+    if used % ncols:
+        rows1 += tasks[used - 1][0] * (used % ncols) / ncols
+    cores = os.cpu_count() or 1
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    out = {"value": round(bytes1 / dt1 / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port", "mrows_per_s": round(rows1 / dt1 / 1e6, 3),
+           "sample": "%d of %d (stripe, column) tasks of the same workload (%.1f stripes), batch 8192, oracle/liborc_oracle.so; the Rust "
+                     "reference itself cannot be built or timed here (no cargo/rustc)" % (used, len(tasks), used / ncols),
+           "cpu_model": model, "host_cores": cores}
+    if cores > 1:
+        # all cores: as many tasks as ~budget_s of wall time allows at the measured single-thread rate
+        per_task = dt1 / used
+        ntask = int(min(len(tasks), max(cores, budget_s * cores / per_task)))
+        ntask -= ntask % ncols if ntask >= ncols else 0
+        sel = list(range(max(ntask, min(len(tasks), cores))))
+        sel.sort(key=lambda i: -sum(len(v) for v in tasks[i][2].values()))  # longest first
+        with mp.get_context("fork").Pool(cores) as pool:
+            pool.map(_oracle_stripe, sel[:cores], chunksize=1)  # start the workers (library load) outside the timed region
+            t0 = time.perf_counter()
+            res = pool.map(_oracle_stripe, sel, chunksize=1)
+            dtn = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(sum(r[1] for r in res) / dtn / 1e9, 4), "unit": "GB/s", "cores": cores,
+                            "mrows_per_s": round(sum(r[0] for r in res) / ncols / dtn / 1e6, 3),
+                            "sample": "%d (stripe, column) tasks over %d processes" % (len(sel), cores)}
+    return out
 
 
 def main():
@@ -94,19 +177,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=ROWS_TOTAL)
+    ap.add_argument("--workload", default="lineitem", choices=["lineitem", "c2", "c2-direct", "c2-delta", "c2-arange", "c3", "c5"],
+                    help="lineitem (default) = the headline; the others are BASELINE.md's remaining configs, recorded under profiles/")
+    ap.add_argument("--compression", default=None, choices=[None, "none", "zstd", "snappy", "lz4", "zlib"])
+    ap.add_argument("--rows", type=int, default=0, help="0 = the config's own size")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--kind", default="mix", choices=["mix", "direct", "delta", "arange"], help="mix = the headline 50/50 workload")
-    ap.add_argument("--skip-check", action="store_true", help="profiling runs: skip the full-size parity properties (12 k small D2H copies)")
+    ap.add_argument("--skip-check", action="store_true", help="profiling runs: skip the full-size check (thousands of small D2H copies)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d needs %d ranks (WORLD_SIZE=%d): launch it with `python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ...`" % (args.gpus, args.gpus, world, args.gpus, args.gpus))
+    # The workload and the CPU baseline come first: the baseline forks worker processes, which must happen before
+    # this process initialises the GPU.
+    stripes, comp, label, shard_desc = build_workload(args, rank, world)
+    cpu = None
+    if rank == 0 and not args.no_cpu and world == 1 and stripes:  # timed on rank 0 at N=1 only
+        cpu = cpu_baseline(stripes, comp)
     import torch
     dist = None
     # BENCH_BACKEND=gloo is a dry-run aid for boxes with fewer GPUs than ranks (ranks then share devices and
-    # the two tiny collectives run on CPU tensors); the driver's runs use the default, RCCL ("nccl").
+    # the collective runs on CPU tensors); the driver's runs use the default, RCCL ("nccl").
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
@@ -122,97 +216,102 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
 
-    from orc_rust_amd import capi
+    from orc_rust_amd import capi, shard
+    from orc_rust_amd.gen import workloads as W
     ctx = capi.Context(local_rank)
-    stripes = build_workload(args.rows, STRIPE_ROWS, args.kind)
-    cols = [{"column_id": 1, "orc_type": 4, "encoding": 2}]
     torch.cuda.synchronize()
     t_stage = time.perf_counter()
-    staged = [ctx.stage(st["n"], [(1, 1, st["stream"])], cols) for st in stripes]
+    staged = [ctx.stage(n, streams, cols, compression=comp) for n, cols, streams, _ in stripes]
     torch.cuda.synchronize()
-    t_stage = time.perf_counter() - t_stage  # host buffers -> HBM through the pinned bounce buffer (not part of `value`)
+    t_stage = time.perf_counter() - t_stage  # host buffers -> HBM (not part of `value`)
     stream_bytes = sum(s.nbytes() for s in staged)
-    rows = sum(st["n"] for st in stripes)
+    rows = sum(s[0] for s in stripes)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    results = ctx.decode(staged)
-    # parity properties at full size (size independent): first values, xor and wrapping sum per stripe
-    for st, res in zip(stripes, results):
-        assert res.status()[0] == 0, res.status()
-        if args.skip_check:
-            continue
-        v0 = np.frombuffer(res.batch(0, 0)["values"], dtype=np.int64)
-        assert np.array_equal(v0[:4], st["first"])
-        nb = res.n_batches
-        acc_x, acc_s = np.uint64(0), np.uint64(0)
-        for b in range(nb):
-            vb = np.frombuffer(res.batch(b, 0)["values"], dtype=np.uint64)
-            acc_x ^= np.bitwise_xor.reduce(vb)
-            acc_s = np.uint64((int(acc_s) + int(vb.sum(dtype=np.uint64))) & ((1 << 64) - 1))
-        assert int(acc_x) == st["xor"] and int(acc_s) == st["sum"], "GPU decode differs from the generated values"
+    results = ctx.decode(staged) if staged else []
+    err_word = 0
+    for (n, cols, streams, expect), res in zip(stripes, results):
+        st = res.status()
+        err_word |= st[0]
+        assert st[0] == 0, st
+        if not args.skip_check:
+            # full-size check: every decoded Arrow buffer equals what the generated values imply
+            W.check_result(res, cols, expect)
     arrow_bytes = sum(r.arrow_bytes for r in results)
 
     for _ in range(args.warmup):
-        ctx.decode(staged, results)
+        if staged:
+            ctx.decode(staged, results)
     barrier()
     t0 = time.perf_counter()
-    exp_ms = 0.0
+    phase = {k: 0.0 for k in capi.Context.PHASES}
     tot_ms = 0.0
     for _ in range(args.steps):
-        ctx.decode(staged, results)
-        t, e, _n = ctx.timing()
-        exp_ms += e
-        tot_ms += t
+        if staged:
+            ctx.decode(staged, results)
+            tot_ms += ctx.timing()[0]
+            for k, v in ctx.phase_ms().items():
+                phase[k] += v
     barrier()
     dt = time.perf_counter() - t0
+    string_bytes = sum(sum(len(e["values"]) for cid, e in expect.items() if "lengths" in e) for _, _, _, expect in stripes)
     if dist is not None:
         tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        # the path's only exchange: per-rank row counts (so every rank knows the global row offsets)
-        cnt = torch.tensor([rows], device=coll_dev, dtype=torch.int64)
-        allc = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(allc, cnt)
-        total_rows = int(sum(int(c.item()) for c in allc))
+        # the path's only exchange: {rows, value bytes of this rank's string columns, Arrow bytes, stream bytes, columns, error word}
+        ncols = len(stripes[0][1]) if stripes else 0
+        allc = shard.gather_counts([rows, string_bytes, arrow_bytes, stream_bytes, ncols, err_word], dist, coll_dev)
+        total_arrow = sum(c[2] for c in allc)
+        total_stream = sum(c[3] for c in allc)
+        assert all(c[5] == 0 for c in allc), "a rank reported a decode error"
+        if args.workload == "lineitem":
+            per_rank_rows = {c[0] for c in allc if c[4]}
+            assert len(per_rank_rows) == 1, "column shards disagree on the row count: %s" % allc
+            assert sum(c[4] for c in allc) == 16, "every column must be decoded exactly once"
+            total_rows = per_rank_rows.pop()
+        else:
+            total_rows = sum(c[0] for c in allc)
+        per_rank = [{"rows": c[0], "string_bytes": c[1], "arrow_bytes": c[2], "stream_bytes": c[3], "columns": c[4]} for c in allc]
     else:
-        total_rows = rows
+        total_rows, total_arrow, total_stream = rows, arrow_bytes, stream_bytes
+        per_rank = None
     ms_per_step = dt / args.steps * 1e3
-    value = arrow_bytes * world / (dt / args.steps) / 1e9
-    exp_avg_ms = exp_ms / args.steps
-    algo_bytes = stream_bytes + arrow_bytes  # staged stream bytes in + Arrow bytes out
-    achieved = algo_bytes / (exp_avg_ms * 1e-3) / 1e9 if exp_avg_ms > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("rle2_expand_kernel_bytes_per_launch")
-        except Exception:
-            traffic = None
+    value = total_arrow / (dt / args.steps) / 1e9
+    phase = {k: v / args.steps for k, v in phase.items()}
+    dom = max(phase, key=lambda k: phase[k]) if staged else "expand"
+    dom_ms = phase[dom]
+    algo_bytes = stream_bytes + arrow_bytes  # staged stream bytes in + Arrow bytes out (this rank's launch)
+    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     out = {
-        "metric": "decoded GB/s + Mrows/s into Arrow", "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int64", "data": "synthetic",
-        "config": {"workload": "C2: RLEv2 DIRECT(48-bit)/DELTA(8-bit) 50/50 Int64 column, %d rows, uncompressed, %d stripes" % (rows, len(stripes))
-                   if args.kind == "mix" else "C2 variant '%s': Int64 column, %d rows, uncompressed, %d stripes" % (args.kind, rows, len(stripes)),
-                   "rows_per_gpu": rows, "stripe_rows": STRIPE_ROWS, "batch_size": 8192, "parallelism": "stripe-shard x%d" % world},
+        "metric": "decoded GB/s + Mrows/s into Arrow, TPC-H lineitem stripe" if args.workload == "lineitem" else "decoded GB/s + Mrows/s into Arrow",
+        "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "dtype": "int64" if args.workload.startswith(("c2", "c5")) else ("u8" if args.workload == "c3" else "int64/i128/u8"),
+        "data": "synthetic",
+        "config": {"workload": label, "rows": total_rows, "stripes": len(stripes), "batch_size": 8192, "compression": comp,
+                   "parallelism": shard_desc},
         "mrows_per_s": round(total_rows / (dt / args.steps) / 1e6, 1),
-        "stream_bytes_in": stream_bytes, "arrow_bytes_out": arrow_bytes,
+        "stream_bytes_in": total_stream, "arrow_bytes_out": total_arrow,
         "device_ms_per_step": round(tot_ms / args.steps, 4),
-        # staging the host stream buffers (pinned bounce buffer + hipMemcpyAsync) is outside the timed region;
-        # the PCIe-inclusive rate is reported for DESIGN.md only
+        "phase_ms": {k: round(v, 4) for k, v in phase.items()},
+        # staging the host stream buffers is outside the timed region; the PCIe-inclusive rate is reported for DESIGN.md only
         "h2d_stage_ms": round(t_stage * 1e3, 3),
         "pcie_inclusive_GBps": round(arrow_bytes / (t_stage + dt / args.steps) / 1e9, 2),
-        "roofline": {"bound": "hbm", "kernel": "rle2_expand_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
-                     "kernel_ms": round(exp_avg_ms, 4)},
+        "roofline": {"bound": "hbm", "kernel": PHASE_KERNELS[dom], "phase": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                     "kernel_ms": round(dom_ms, 4),
+                     "whole_step_frac": round(algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)},
     }
+    if per_rank is not None:
+        out["per_rank"] = per_rank
     if rank == 0:
-        if not args.no_cpu and world == 1:  # timed on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(stripes)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

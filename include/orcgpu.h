@@ -196,6 +196,13 @@ int orcgpu_reader_next_batch(orcgpu_reader* r, struct ArrowArray* out_array, str
 /* Milliseconds the device spent in the last orcgpu_decode_staged call, whole call and the RLE
  * expansion kernels alone (the dominant kernel), measured with hipEvents on the ctx stream. */
 int orcgpu_last_timing(const orcgpu_ctx* ctx, float* total_ms, float* expand_ms, uint32_t* expand_launches);
+/* The same call split into the phases of the pipeline (HIP events between them, same stream):
+ *   0 block decompression (compression.rs:142-195)      1 run-boundary walk + output position scans
+ *   2 PRESENT streams -> validity / ranks               3 RLE expansion (the three *_expand kernels)
+ *   4 finishers (null spacing, strings, decimals, timestamps) + the summary copy
+ * ms[0..n) receives the first n of them. */
+#define ORCGPU_N_PHASES 5
+int orcgpu_last_phase_ms(const orcgpu_ctx* ctx, float* ms, uint32_t n);
 
 #ifdef __cplusplus
 }

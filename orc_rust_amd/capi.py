@@ -20,7 +20,7 @@ EXPORTS = [
     "orcgpu_open", "orcgpu_close", "orcgpu_last_error", "orcgpu_version", "orcgpu_stage_stripe", "orcgpu_staged_free",
     "orcgpu_staged_bytes", "orcgpu_decode_staged", "orcgpu_stripe_decode", "orcgpu_result_free", "orcgpu_result_status",
     "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
-    "orcgpu_result_copy_batch", "orcgpu_result_export_batch", "orcgpu_last_timing",
+    "orcgpu_result_copy_batch", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
     "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
     "orcgpu_reader_set_projection", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision",
     "orcgpu_reader_total_rows", "orcgpu_reader_stripe_count", "orcgpu_reader_column_count", "orcgpu_reader_column_name",
@@ -92,6 +92,7 @@ def load():
     L.orcgpu_result_copy_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orcgpu_result_export_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.orcgpu_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.orcgpu_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
     L.orcgpu_reader_open_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
     L.orcgpu_reader_open_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]
     L.orcgpu_reader_close.argtypes = [C.c_void_p]
@@ -180,6 +181,15 @@ class Context:
         a, b, c = C.c_float(), C.c_float(), C.c_uint32()
         self.L.orcgpu_last_timing(self.h, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
+
+
+    PHASES = ("decompress", "walk", "present", "expand", "finish")
+
+    def phase_ms(self):
+        """Device milliseconds of the last decode call per pipeline phase (orcgpu_last_phase_ms)."""
+        a = (C.c_float * 5)()
+        self.L.orcgpu_last_phase_ms(self.h, a, 5)
+        return dict(zip(self.PHASES, [float(x) for x in a]))
 
 
 class Staged:

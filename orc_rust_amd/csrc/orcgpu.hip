@@ -126,8 +126,9 @@ struct orcgpu_ctx {
   DevBuf scratch;
   uint8_t* pinned = nullptr;
   size_t pinned_cap = 0;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk
   float last_total_ms = 0, last_expand_ms = 0;
+  float last_phase_ms[ORCGPU_N_PHASES] = {0, 0, 0, 0, 0};
   uint32_t last_expand_launches = 0;
   bool ensure_pinned(size_t n) {
     if (n <= pinned_cap) return true;

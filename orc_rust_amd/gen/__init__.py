@@ -10,14 +10,30 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "orcgen.c")
+SRCS = [os.path.join(HERE, "orcgen.c"), os.path.join(HERE, "tpchgen.c")]
 SO = os.path.join(HERE, "liborcgen.so")
 _lib = None
 
 
+def _fresh():
+    return os.path.exists(SO) and all(os.path.getmtime(s) <= os.path.getmtime(SO) for s in SRCS)
+
+
 def build(force=False):
-    if force or not os.path.exists(SO) or os.path.getmtime(SRC) > os.path.getmtime(SO):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-o", SO, SRC])
+    """Compiles liborcgen.so in-tree.  Safe with several ranks starting at once: one builds under a file
+    lock into a temporary name that replaces the library atomically (same scheme as orc_rust_amd/build.py)."""
+    import fcntl
+    if not force and _fresh():
+        return SO
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not _fresh():
+                tmp = SO + ".tmp.%d" % os.getpid()
+                subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-o", tmp] + SRCS)
+                os.replace(tmp, SO)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return SO
 
 
@@ -34,6 +50,9 @@ def lib():
         L.orcgen_compress_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, pp, ps]
         L.orcgen_free.argtypes = [C.c_void_p]
         L.orcgen_splitmix64.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
+        L.orcgen_varint64.argtypes = [C.c_void_p, C.c_size_t, pp, ps]
+        L.orcgen_lineitem.restype = C.c_uint64
+        L.orcgen_lineitem.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
         _lib = L
     return _lib
 
@@ -83,6 +102,14 @@ def varint128(values):
         arr[2 * i + 1] = u >> 64
     out, n = C.c_void_p(), C.c_size_t()
     lib().orcgen_varint128(arr.ctypes.data, len(values), C.byref(out), C.byref(n))
+    return _take(out, n)
+
+
+def varint64(values):
+    """zigzag varints of an int64 array (Decimal DATA of precision <= 18)."""
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    out, n = C.c_void_p(), C.c_size_t()
+    lib().orcgen_varint64(v.ctypes.data, v.size, C.byref(out), C.byref(n))
     return _take(out, n)
 
 

@@ -1,0 +1,78 @@
+"""BASELINE.md's workload SHAPES on the HIP path (through the C ABI), batch by batch against the CPU oracle and against
+the buffers the generated values imply:
+
+  C4  TPC-H-shaped lineitem stripes, 16 columns, Zstandard (and uncompressed), two stripes in one decode call
+  C5  Timestamp(ns) with an all-PATCHED_BASE seconds stream + DIRECT nanoseconds, LZ4
+  C3  dictionary Utf8 + PRESENT, Snappy
+
+at 1-2 M rows (the oracle finishes in seconds); bench.py runs the same generators at full size with the
+generator-implied check (`workloads.check_result`)."""
+import numpy as np
+import pytest
+
+import gpu_util as G
+from orc_rust_amd.gen import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def decode_all(stripes, compression):
+    c = G.ctx()
+    staged = [c.stage(n, streams, cols, compression=compression) for n, cols, streams, *_ in stripes]
+    results = c.decode(staged)
+    for s in staged:
+        s.free()
+    return results
+
+
+@pytest.mark.parametrize("compression", ["zstd", "none"])
+def test_c4_lineitem_stripes(compression):
+    rows = 1_300_000
+    table = W.lineitem_table(rows)
+    stripes = [W.lineitem_stripe(table, 0, 1_000_000, compression), W.lineitem_stripe(table, 1_000_000, rows, compression)]
+    results = decode_all(stripes, compression)
+    for (n, cols, streams, expect), res in zip(stripes, results):
+        assert res.status()[0] == 0, res.status()
+        assert res.rows == n and res.n_batches == (n + 8191) // 8192
+        W.check_result(res, cols, expect)
+        for ci, c in enumerate(cols):
+            G.assert_column_parity(res, ci, c, streams, n, 8192, compression=compression, what=("C4", compression, c["name"]))
+        res.free()
+
+
+def test_c4_lineitem_column_shard_equals_the_full_decode():
+    """A column shard (the multi-GPU partition of C4) decodes to the same buffers as the same columns of a full decode."""
+    rows = 200_000
+    table = W.lineitem_table(rows)
+    full = W.lineitem_stripe(table, 0, rows, "zstd")
+    mine = [2, 5, 9, 16]
+    part = W.lineitem_stripe(table, 0, rows, "zstd", column_ids=mine)
+    rf, rp = decode_all([full], "zstd")[0], decode_all([part], "zstd")[0]
+    for pi, c in enumerate(part[1]):
+        fi = [k for k, fc in enumerate(full[1]) if fc["column_id"] == c["column_id"]][0]
+        for b in range(rf.n_batches):
+            x, y = rf.batch(b, fi), rp.batch(b, pi)
+            assert x["values"] == y["values"] and x["null_count"] == y["null_count"]
+            assert (x["offsets"] is None) == (y["offsets"] is None) and (x["offsets"] is None or np.array_equal(x["offsets"], y["offsets"]))
+    rf.free()
+    rp.free()
+
+
+def test_c5_patched_base_timestamps_lz4():
+    stripes = [W.c5_stripe(1_048_576, 0), W.c5_stripe(700_001, 1)]
+    assert all(s[4]["patched_base"] == (s[0] + 511) // 512 for s in stripes)
+    results = decode_all(stripes, "lz4")
+    for (n, cols, streams, expect, _), res in zip(stripes, results):
+        W.check_result(res, cols, expect)
+        G.assert_column_parity(res, 0, cols[0], streams, n, 8192, compression="lz4", what="C5")
+        res.free()
+
+
+@pytest.mark.parametrize("compression", ["snappy", "zstd"])
+def test_c3_dictionary_utf8_with_present(compression):
+    stripes = [W.c3_stripe(1_500_000, 0, compression), W.c3_stripe(300_000, 1, compression)]
+    results = decode_all(stripes, compression)
+    for (n, cols, streams, expect), res in zip(stripes, results):
+        W.check_result(res, cols, expect)
+        G.assert_column_parity(res, 0, cols[0], streams, n, 8192, compression=compression, what=("C3", compression))
+        res.free()

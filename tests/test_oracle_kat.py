@@ -2,6 +2,7 @@
 unit tests (sources cited per test)."""
 import numpy as np
 
+import kat_vectors as K
 import oracle_lib as O
 
 
@@ -41,26 +42,7 @@ def test_rlev2_patched_base():  # rle_v2/mod.rs:650-659
         [2030, 2000, 2020, 1000000, 2040, 2050, 2060, 2070, 2080, 2090])
 
 
-PATCHED_1 = [
-    144, 109, 4, 164, 141, 16, 131, 194, 0, 240, 112, 64, 60, 84, 24, 3, 193, 201, 128, 120, 60, 33, 4, 244, 3, 193, 192, 224,
-    128, 56, 32, 15, 22, 131, 129, 225, 0, 112, 84, 86, 14, 8, 106, 193, 192, 228, 160, 64, 32, 14, 213, 131, 193, 192, 240, 121,
-    124, 30, 18, 9, 132, 67, 0, 224, 120, 60, 28, 14, 32, 132, 65, 192, 240, 160, 56, 61, 91, 7, 3, 193, 192, 240, 120, 76, 29,
-    23, 7, 3, 220, 192, 240, 152, 60, 52, 15, 7, 131, 129, 225, 0, 144, 56, 30, 14, 44, 140, 129, 194, 224, 120, 0, 28, 15, 8,
-    6, 129, 198, 144, 128, 104, 36, 27, 11, 38, 131, 33, 48, 224, 152, 60, 111, 6, 183, 3, 112, 0, 1, 78, 5, 46, 2, 1, 1, 141,
-    3, 1, 1, 138, 22, 0, 65, 1, 4, 0, 225, 16, 209, 192, 4, 16, 8, 36, 16, 3, 48, 1, 3, 13, 33, 0, 176, 0, 1, 94, 18, 0, 68, 0,
-    33, 1, 143, 0, 1, 7, 93, 0, 25, 0, 5, 0, 2, 0, 4, 0, 1, 0, 1, 0, 2, 0, 16, 0, 1, 11, 150, 0, 3, 0, 1, 0, 1, 99, 157, 0, 1,
-    140, 54, 0, 162, 1, 130, 0, 16, 112, 67, 66, 0, 2, 4, 0, 0, 224, 0, 1, 0, 16, 64, 16, 91, 198, 1, 2, 0, 32, 144, 64, 0, 12,
-    2, 8, 24, 0, 64, 0, 1, 0, 0, 8, 48, 51, 128, 0, 2, 12, 16, 32, 32, 71, 128, 19, 76,
-]
-PATCHED_1_EXPECTED = [
-    20, 2, 3, 2, 1, 3, 17, 71, 35, 2, 1, 139, 2, 2, 3, 1783, 475, 2, 1, 1, 3, 1, 3, 2, 32, 1, 2, 3, 1, 8, 30, 1, 3, 414, 1, 1,
-    135, 3, 3, 1, 414, 2, 1, 2, 2, 594, 2, 5, 6, 4, 11, 1, 2, 2, 1, 1, 52, 4, 1, 2, 7, 1, 17, 334, 1, 2, 1, 2, 2, 6, 1, 266, 1,
-    2, 217, 2, 6, 2, 13, 2, 2, 1, 2, 3, 5, 1, 2, 1, 7244, 11813, 1, 33, 2, -13, 1, 2, 3, 13, 1, 92, 3, 13, 5, 14, 9, 141, 12, 6,
-    15, 25, -1, -1, -1, 23, 1, -1, -1, -71, -2, -1, -1, -1, -1, 2, 1, 4, 34, 5, 78, 8, 1, 2, 2, 1, 9, 10, 2, 1, 4, 13, 1, 5, 4,
-    4, 19, 5, -1, -1, -1, 34, -17, -200, -1, -943, -13, -3, 1, 2, -1, -1, 1, 8, -1, 1483, -2, -1, -1, -12751, -1, -1, -1, 66, 1,
-    3, 8, 131, 14, 5, 1, 2, 2, 1, 1, 8, 1, 1, 2, 1, 5, 9, 2, 3, 112, 13, 2, 2, 1, 5, 10, 3, 1, 1, 13, 2, 3, 4, 1, 3, 1, 1, 2, 1,
-    1, 2, 4, 2, 207, 1, 1, 2, 4, 3, 3, 2, 2, 16,
-]
+from kat_vectors import PATCHED_1, PATCHED_1_EXPECTED  # noqa: E402
 
 
 def test_rlev2_patched_base_java():  # rle_v2/mod.rs:662-692 (Java-generated, 226 values)
@@ -68,6 +50,21 @@ def test_rlev2_patched_base_java():  # rle_v2/mod.rs:662-692 (Java-generated, 22
     # in batches that straddle the run
     st, got = O.int_rle(bytes(PATCHED_1), 226, signed=True, chunks=[7, 100, 119])
     assert st == O.OK and got.tolist() == PATCHED_1_EXPECTED
+
+
+def test_every_shared_vector():
+    """tests/kat_vectors.py: the same bytes tests/test_gpu_kat.py feeds to the HIP path."""
+    for name, data, want, signed, version, nbits in K.INT_RLE:
+        st, got = O.int_rle(bytes(data), len(want), version=version, signed=signed, nbits=nbits)
+        assert st == O.OK and got.tolist() == list(want), name
+    for name, data, want in K.BYTE_RLE:
+        st, v = O.byte_rle(bytes(data), len(want))
+        assert st == O.OK and (v.astype(np.int64) & 0xFF).tolist() == want, name
+    for name, data, want in K.BOOLEAN:
+        st, v = O.boolean(bytes(data), len(want))
+        assert st == O.OK and v.tolist() == want, name
+    for name, data, want in K.VARINT_I128:
+        assert O.varint128(bytes(data), len(want)) == (O.OK, want), name
 
 
 def test_rlev2_eof_is_out_of_spec():  # rle_v2/mod.rs:118-126
