@@ -22,7 +22,10 @@ struct ChunkDesc {
   uint32_t kind;        // 0 = original (copy), else ORCGPU_COMP_*
   uint32_t stream;      // index into the per-stream tables
   uint32_t out_len;     // written by the kernel
-  uint32_t status;      // 0 ok, else ORC_E_CODEC
+  uint32_t status;      // 0 ok, else ORC_E_CODEC (Zstandard: preset by the host when the frame / block headers do not parse)
+  uint32_t first_item, n_items;  // Zstandard: the chunk's blocks in the ZItem table (lz_exec.h)
+  uint32_t diag;        // diagnostics: where a rejected chunk failed
+  uint32_t pad;
 };
 
 struct StreamDesc {
@@ -634,11 +637,13 @@ __device__ __forceinline__ int lz4_wave(const uint8_t* src, uint32_t n, uint8_t*
 
 #include "inflate_device.h"
 #include "zstd_device.h"
+#include "zstd_entropy.h"
+#include "lz_exec.h"
 
-// One kernel per codec family (a single kernel with all four inlined runs out of scalar registers and
-// carries every family's LDS): `family` 0 = Snappy / LZ4, 1 = DEFLATE, 2 = Zstandard.  Each launch
-// covers the whole chunk table and takes the chunks of its family; "original" chunks (plain copies)
-// belong to whichever family the host launches first (copy_too).
+// One kernel per codec family (a single kernel with all of them inlined runs out of scalar registers and
+// carries every family's LDS): `family` 0 = Snappy / LZ4, 1 = DEFLATE; Zstandard has its own two kernels
+// (zstd_entropy.h, lz_exec.h).  Each launch covers the whole chunk table and takes the chunks of its
+// family; "original" chunks (plain copies) belong to whichever family the host launches first (copy_too).
 template <int FAMILY>
 __device__ __forceinline__ void decompress_chunks_body(ChunkDesc* chunks, uint32_t n_chunks, int copy_too, DecompLds* tables, LzLds lz) {
   uint32_t c = blockIdx.x;
@@ -647,7 +652,7 @@ __device__ __forceinline__ void decompress_chunks_body(ChunkDesc* chunks, uint32
   PROF_BEGIN();
   ChunkDesc d = chunks[c];
   const bool mine = (d.kind == 0 && copy_too) || (FAMILY == 0 && (d.kind == 2 || d.kind == 4)) || (FAMILY == 1 && d.kind == 1) ||
-                    (FAMILY == 2 && d.kind == 5) || (copy_too && d.kind != 0 && d.kind != 1 && d.kind != 2 && d.kind != 4 && d.kind != 5);
+                    (copy_too && d.kind != 0 && d.kind != 1 && d.kind != 2 && d.kind != 4 && d.kind != 5);
   if (!mine) return;
   d.src = as_global(d.src);  // plain global memory, not generic: see as_global()
   d.dst = (uint8_t*)as_global((void*)d.dst);
@@ -666,8 +671,6 @@ __device__ __forceinline__ void decompress_chunks_body(ChunkDesc* chunks, uint32
     bad = lz4_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, lz PROF_ARG);
   } else if (FAMILY == 1 && d.kind == 1) {
     bad = inflate_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, *tables, lz);
-  } else if (FAMILY == 2 && d.kind == 5) {
-    bad = zstd_wave(d.src, d.src_len, d.dst, d.dst_cap, d.scratch, lane, &out_len, *tables, lz PROF_ARG);
   } else {
     bad = 1;  // unknown compression kind
   }
@@ -686,11 +689,6 @@ extern "C" __global__ void __launch_bounds__(64) decompress_deflate_kernel(Chunk
   __shared__ DecompLds lds;
   __shared__ __attribute__((aligned(16))) LzStore<32768> lz;
   decompress_chunks_body<1>(chunks, n_chunks, copy_too, &lds, lz_view(lz));
-}
-extern "C" __global__ void __launch_bounds__(64) decompress_zstd_kernel(ChunkDesc* chunks, uint32_t n_chunks, int copy_too) {
-  __shared__ DecompLds lds;
-  __shared__ __attribute__((aligned(16))) LzStore<32768> lz;
-  decompress_chunks_body<2>(chunks, n_chunks, copy_too, &lds, lz_view(lz));
 }
 
 // One workgroup per stream: make the plain chunks contiguous (they already are unless a chunk in

@@ -1,11 +1,8 @@
-// zstd_device.h -- Zstandard frame decoder (RFC 8878) for one wavefront.  Replaces zstd::Decoder at
-// compression.rs:151-159.  No dictionaries; the content checksum is skipped, not verified.
-//
-// Per compressed block: the literals section is decoded first (4 Huffman streams -> lanes 0..3
-// decode one stream each; raw literals are used in place), then the sequence section is decoded
-// wave-uniformly (three interleaved FSE states read backwards) and each sequence is executed by
-// all lanes: literal copy from the literal buffer + LZ77 match copy.  FSE/Huffman tables live in
-// LDS; decoded literals of a block (<= 128 KiB) go to a per-chunk scratch area in HBM.
+// zstd_device.h -- building blocks of the Zstandard decoder (RFC 8878; replaces zstd::Decoder at
+// compression.rs:151-159; no dictionaries; the content checksum is skipped, not verified): constant
+// tables, the backward bit reader, FSE table descriptions and tables, Huffman tables and the
+// many-lanes-per-stream Huffman decoder.  The decoder itself is split in two kernels:
+// zstd_entropy.h (one wavefront per compressed block) and lz_exec.h (one workgroup per chunk).
 #pragma once
 
 __device__ const int16_t Z_LL_DEF[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
@@ -221,21 +218,6 @@ __device__ __forceinline__ int huf_build_dev(uint16_t* tab, int* maxbits_out, ui
   return bad;
 }
 
-// one Huffman stream, executed by ONE lane (others predicated off by the caller)
-__device__ __forceinline__ int huf_decode_stream_dev(const uint16_t* tab, int mb, const uint8_t* p, uint32_t n, uint8_t* out, uint32_t outn) {
-  RBits r;
-  if (!rb_init(r, p, n)) return 1;
-  uint32_t state = (uint32_t)rb_read(r, (uint32_t)mb);
-  uint32_t mask = (1u << mb) - 1;
-  for (uint32_t i = 0; i < outn; i++) {
-    uint32_t e = tab[state];
-    out[i] = (uint8_t)e;
-    uint32_t nb = e >> 8;
-    state = ((state << nb) & mask) | (uint32_t)rb_read(r, nb);
-  }
-  return r.bits != -(long)mb;
-}
-
 // Huffman streams decoded by MANY lanes each (16 per stream for the usual four streams, 64 for a single
 // one).  A stream is a chain of prefix codes read downwards from its top bit; lane k of a stream starts
 // at bit top - k*B (not a code boundary in general), decodes down to the start of the next lane's
@@ -342,414 +324,4 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
     for (uint32_t t = 0; t < nacc; t++) out[i + t] = (uint8_t)(acc >> (8 * t));
   }
   return bad;
-}
-
-struct ZState {
-  int huf_valid, huf_bits;
-  int ll_valid, of_valid, ml_valid;
-  int ll_log, of_log, ml_log;
-  uint32_t rep[3];
-};
-
-// literals section: returns bytes consumed (<0 error); *lit/*litn describe the decoded literals
-__device__ __forceinline__ long z_literals_dev(ZState& z, DecompLds& L, const uint8_t* p, uint32_t n, uint8_t* scratch, const uint8_t** lit,
-                                               uint32_t* litn, uint32_t lane PROF_PARM) {
-  if (n < 1) return -1;
-  uint32_t type = p[0] & 3, sf = (p[0] >> 2) & 3;
-  uint32_t regen, comp = 0, hdr;
-  int streams = 1;
-  if (type < 2) {
-    if (sf == 0 || sf == 2) {
-      regen = p[0] >> 3;
-      hdr = 1;
-    } else if (sf == 1) {
-      if (n < 2) return -1;
-      regen = (p[0] >> 4) | ((uint32_t)p[1] << 4);
-      hdr = 2;
-    } else {
-      if (n < 3) return -1;
-      regen = (p[0] >> 4) | ((uint32_t)p[1] << 4) | ((uint32_t)p[2] << 12);
-      hdr = 3;
-    }
-    if (regen > 128 * 1024) return -1;
-    if (type == 0) {
-      if (hdr + regen > n) return -1;
-      *lit = p + hdr;
-      *litn = regen;
-      return (long)(hdr + regen);
-    }
-    if (hdr + 1 > n || !scratch) return -1;
-    uint8_t v = p[hdr];
-    for (uint32_t k = lane; k < regen; k += 64) scratch[k] = v;
-    wave_fence();
-    *lit = scratch;
-    *litn = regen;
-    return (long)(hdr + 1);
-  }
-  if (sf == 0 || sf == 1) {
-    if (n < 3) return -1;
-    uint32_t v = p[0] | (p[1] << 8) | (p[2] << 16);
-    regen = (v >> 4) & 0x3ff;
-    comp = (v >> 14) & 0x3ff;
-    hdr = 3;
-    streams = sf == 0 ? 1 : 4;
-  } else if (sf == 2) {
-    if (n < 4) return -1;
-    uint32_t v = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
-    regen = (v >> 4) & 0x3fff;
-    comp = (v >> 18) & 0x3fff;
-    hdr = 4;
-    streams = 4;
-  } else {
-    if (n < 5) return -1;
-    uint64_t v = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint64_t)p[3] << 24) | ((uint64_t)p[4] << 32);
-    regen = (uint32_t)((v >> 4) & 0x3ffff);
-    comp = (uint32_t)((v >> 22) & 0x3ffff);
-    hdr = 5;
-    streams = 4;
-  }
-  if (regen > 128 * 1024 || hdr + comp > n || !scratch) return -1;
-  const uint8_t* q = p + hdr;
-  uint32_t qn = comp;
-  if (type == 2) {
-    if (qn < 1) return -1;
-    int nw;
-    uint32_t hb = q[0];
-    uint32_t used;
-    if (hb >= 128) {
-      nw = (int)hb - 127;
-      uint32_t nbytes = (uint32_t)(nw + 1) / 2;
-      if (1 + nbytes > qn) return -1;
-      for (int i = (int)lane; i < nw; i += 64) L.z.weights[i] = (i & 1) ? (q[1 + i / 2] & 15) : (q[1 + i / 2] >> 4);
-      used = 1 + nbytes;
-      wave_sync();
-    } else {
-      if (1 + hb > qn) return -1;
-      int nsym = 256, log;
-      long c = fse_read_ncount_dev(q + 1, hb, L.z.norm, &nsym, &log, 6, lane);
-      if (c < 0) return -1;
-      if (fse_build_dev(L.z.wt, L.z.norm, nsym, log, L.z.next, lane)) return -1;
-      RBits r;
-      if (!rb_init(r, q + 1 + c, hb - (uint32_t)c)) return -1;
-      uint32_t s1 = (uint32_t)rb_read(r, (uint32_t)log), s2 = (uint32_t)rb_read(r, (uint32_t)log);
-      nw = 0;
-      int fail = 0;
-      for (;;) {
-        if (nw >= 254) {
-          fail = 1;
-          break;
-        }
-        if (lane == 0) L.z.weights[nw] = L.z.wt[s1].sym;
-        nw++;
-        if (r.bits < (long)L.z.wt[s1].nb) {
-          if (lane == 0) L.z.weights[nw] = L.z.wt[s2].sym;
-          nw++;
-          break;
-        }
-        s1 = L.z.wt[s1].base + (uint32_t)rb_read(r, L.z.wt[s1].nb);
-        if (nw >= 254) {
-          fail = 1;
-          break;
-        }
-        if (lane == 0) L.z.weights[nw] = L.z.wt[s2].sym;
-        nw++;
-        if (r.bits < (long)L.z.wt[s2].nb) {
-          if (lane == 0) L.z.weights[nw] = L.z.wt[s1].sym;
-          nw++;
-          break;
-        }
-        s2 = L.z.wt[s2].base + (uint32_t)rb_read(r, L.z.wt[s2].nb);
-      }
-      if (fail) return -1;
-      used = 1 + hb;
-      wave_sync();
-    }
-    PROF_MARK(5);
-    if (huf_build_dev(L.z.huf, &z.huf_bits, L.z.weights, nw, lane)) return -1;
-    PROF_MARK(6);
-    z.huf_valid = 1;
-    q += used;
-    qn -= used;
-  } else if (!z.huf_valid) {
-    return -1;
-  }
-  PROF_MARK(7);
-  int bad = 0;
-  if (streams == 1) {
-    bad = huf_decode_par(L.z.huf, z.huf_bits, q, qn, scratch, regen, lane, 64, true);
-  } else {
-    if (qn < 6) return -1;
-    uint32_t s1 = q[0] | (q[1] << 8), s2 = q[2] | (q[3] << 8), s3 = q[4] | (q[5] << 8);
-    if (6 + s1 + s2 + s3 > qn) return -1;
-    uint32_t s4 = qn - 6 - s1 - s2 - s3;
-    uint32_t seg = (regen + 3) / 4;
-    if (seg * 3 > regen) return -1;
-    const uint8_t* b = q + 6;
-    const uint32_t st = lane >> 4;  // stream of this lane (16 lanes each)
-    uint32_t so = st == 0 ? 0 : (st == 1 ? s1 : (st == 2 ? s1 + s2 : s1 + s2 + s3));
-    uint32_t sl = st == 0 ? s1 : (st == 1 ? s2 : (st == 2 ? s3 : s4));
-    uint32_t on = st < 3 ? seg : regen - 3 * seg;
-    bad = huf_decode_par(L.z.huf, z.huf_bits, b + so, sl, scratch + st * seg, on, lane & 15, 16, true);
-  }
-  PROF_MARK(8);
-  if (__ballot(bad != 0)) return -1;
-  wave_fence();
-  *lit = scratch;
-  *litn = regen;
-  return (long)(hdr + comp);
-}
-
-__device__ __forceinline__ long z_seq_table_dev(FseEnt* t, int* valid, int* log_io, int mode, const uint8_t* p, uint32_t n, const int16_t* def,
-                                                int defn, int deflog, int maxsym, int maxlog, DecompLds& L, uint32_t lane) {
-  if (mode == 0) {
-    for (int i = (int)lane; i < defn; i += 64) L.z.norm[i] = def[i];
-    wave_sync();
-    if (fse_build_dev(t, L.z.norm, defn, deflog, L.z.next, lane)) return -1;
-    *valid = 1;
-    *log_io = deflog;
-    return 0;
-  }
-  if (mode == 1) {
-    if (n < 1) return -1;
-    if (lane == 0) {
-      t[0].sym = p[0];
-      t[0].nb = 0;
-      t[0].base = 0;
-    }
-    wave_sync();
-    *valid = 1;
-    *log_io = 0;
-    return 1;
-  }
-  if (mode == 2) {
-    int nsym = maxsym, log;
-    long c = fse_read_ncount_dev(p, n, L.z.norm, &nsym, &log, maxlog, lane);
-    if (c < 0) return -1;
-    if (fse_build_dev(t, L.z.norm, nsym, log, L.z.next, lane)) return -1;
-    *valid = 1;
-    *log_io = log;
-    return c;
-  }
-  return *valid ? 0 : -1;
-}
-
-// one compressed block; returns the new output size or -1
-// (returns 0 or -1; the output goes through the LDS window `o`; match distances count from frame_start)
-__device__ __forceinline__ long z_block_dev(ZState& z, DecompLds& L, const uint8_t* p, uint32_t n, LzOut& o, uint64_t frame_start, uint64_t cap,
-                                            uint8_t* scratch, LzLds Z, uint32_t lane PROF_PARM) {
-  const uint8_t* lit = nullptr;
-  uint32_t litn = 0;
-  PROF_MARK(10);
-  long used = z_literals_dev(z, L, p, n, scratch, &lit, &litn, lane PROF_ARG);
-  PROF_MARK(11);
-  if (used < 0) return -1;
-  const uint8_t* q = p + used;
-  uint32_t qn = n - (uint32_t)used;
-  if (qn < 1) return -1;
-  uint32_t nseq;
-  if (q[0] < 128) {
-    nseq = q[0];
-    q += 1;
-    qn -= 1;
-  } else if (q[0] < 255) {
-    if (qn < 2) return -1;
-    nseq = ((uint32_t)(q[0] - 128) << 8) + q[1];
-    q += 2;
-    qn -= 2;
-  } else {
-    if (qn < 3) return -1;
-    nseq = (uint32_t)q[1] + ((uint32_t)q[2] << 8) + 0x7f00;
-    q += 3;
-    qn -= 3;
-  }
-  uint32_t lp = 0;
-  if (nseq) {
-    if (qn < 1) return -1;
-    uint32_t modes = q[0];
-    if (modes & 3) return -1;
-    q++;
-    qn--;
-    long c = z_seq_table_dev(L.z.ll, &z.ll_valid, &z.ll_log, (modes >> 6) & 3, q, qn, Z_LL_DEF, 36, 6, 36, 9, L, lane);
-    if (c < 0) return -1;
-    q += c;
-    qn -= (uint32_t)c;
-    c = z_seq_table_dev(L.z.of, &z.of_valid, &z.of_log, (modes >> 4) & 3, q, qn, Z_OF_DEF, 29, 5, 32, 8, L, lane);
-    if (c < 0) return -1;
-    q += c;
-    qn -= (uint32_t)c;
-    c = z_seq_table_dev(L.z.ml, &z.ml_valid, &z.ml_log, (modes >> 2) & 3, q, qn, Z_ML_DEF, 53, 6, 53, 9, L, lane);
-    if (c < 0) return -1;
-    q += c;
-    qn -= (uint32_t)c;
-    RBits r;
-    if (!rb_init(r, q, qn)) return -1;
-    uint32_t sl = (uint32_t)rb_read(r, (uint32_t)z.ll_log);
-    uint32_t so = (uint32_t)rb_read(r, (uint32_t)z.of_log);
-    uint32_t sm = (uint32_t)rb_read(r, (uint32_t)z.ml_log);
-    PROF_MARK(12);
-    // The FSE state machine is serial, the copies are not: sequences are decoded one after the other into
-    // the group table (literal part, match part) and executed 60+ elements at a time by lz_group_run
-    // (wave scan -> output positions, independent copies in parallel).  Literals come from `lit`.
-    LzIn lin{lit, litn, Z.stage, 0};
-    lzin_stage(lin, lp, lane);
-    LzGroup G{0, 0, 0, 0};
-    uint32_t gn = 0;
-    uint64_t vout = o.out;  // output position once everything filed has been executed
-    auto run_group = [&]() -> int {
-      lds_order();
-      G.len = lane < gn ? Z.g_len[lane] : 0;
-      G.off = lane < gn ? Z.g_off[lane] : 0;
-      G.src = lane < gn ? Z.g_src[lane] : 0;
-      G.n = gn;
-      gn = 0;
-      return lz_group_run(G, lin, o, cap, lane PROF_ARG);
-    };
-    for (uint32_t i = 0; i < nseq; i++) {
-      FseEnt el = L.z.ll[sl], eo = L.z.of[so], em = L.z.ml[sm];
-      uint32_t oc = eo.sym, mc = em.sym, lc = el.sym;
-      if (oc > 31 || mc > 52 || lc > 35) return -1;
-      uint64_t ofv = (1ull << oc) + rb_read(r, oc);
-      uint32_t mlen = Z_ML_BASE[mc] + (uint32_t)rb_read(r, Z_ML_BITS[mc]);
-      uint32_t llen = Z_LL_BASE[lc] + (uint32_t)rb_read(r, Z_LL_BITS[lc]);
-      if (r.bits < 0) return -1;
-      uint64_t offset;
-      if (ofv > 3) {
-        offset = ofv - 3;
-        z.rep[2] = z.rep[1];
-        z.rep[1] = z.rep[0];
-        z.rep[0] = (uint32_t)offset;
-      } else {
-        uint32_t idx = (uint32_t)ofv - 1 + (llen == 0 ? 1 : 0);
-        if (idx == 0) {
-          offset = z.rep[0];
-        } else {
-          offset = idx < 3 ? z.rep[idx] : z.rep[0] - 1;
-          if (idx > 1) z.rep[2] = z.rep[1];
-          z.rep[1] = z.rep[0];
-          z.rep[0] = (uint32_t)offset;
-        }
-      }
-      if (offset == 0) return -1;
-      if ((uint64_t)lp + llen > litn || vout + llen + mlen > cap) return -1;
-      if (offset > vout + llen - frame_start) return -1;
-      if (gn > 62 && run_group()) return -1;
-      if (llen > 64) {
-        if (run_group()) return -1;
-        lz_literal(o, lit + lp, llen, lane);
-      } else if (llen) {
-        if (lane == 0) {
-          Z.g_len[gn] = llen;
-          Z.g_off[gn] = 0;
-          Z.g_src[gn] = lp;
-        }
-        gn++;
-      }
-      lp += llen;
-      if (mlen > 64 || offset > 0xffffffffull) {
-        if (run_group()) return -1;
-        if (offset > 0xffffffffull) return -1;
-        lz_match(o, (uint32_t)offset, mlen, lane);
-      } else {
-        if (lane == 0) {
-          Z.g_len[gn] = mlen;
-          Z.g_off[gn] = (uint32_t)offset;
-          Z.g_src[gn] = 0;
-        }
-        gn++;
-      }
-      vout += llen + mlen;
-      if (i + 1 < nseq) {
-        sl = el.base + (uint32_t)rb_read(r, el.nb);
-        sm = em.base + (uint32_t)rb_read(r, em.nb);
-        so = eo.base + (uint32_t)rb_read(r, eo.nb);
-        if (r.bits < 0) return -1;
-      }
-    }
-    if (run_group()) return -1;
-    if (r.bits != 0) return -1;
-  }
-  PROF_MARK(13);
-  if (o.out + (litn - lp) > cap) return -1;
-  lz_literal(o, lit + lp, litn - lp, lane);
-  PROF_MARK(14);
-  return 0;
-}
-
-__device__ __forceinline__ int zstd_wave(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* scratch, uint32_t lane,
-                                          uint32_t* out_len, DecompLds& L, LzLds Z PROF_PARM) {
-  uint32_t pos = 0;
-  LzOut o{Z.ring, Z.rsize - 1, dst, 0, 0};
-  while (pos < n) {
-    if (pos + 4 > n) return 1;
-    uint32_t magic = ld_u32(src + pos);
-    if ((magic & 0xfffffff0u) == 0x184d2a50u) {
-      if (pos + 8 > n) return 1;
-      uint32_t sz = ld_u32(src + pos + 4);
-      if ((uint64_t)pos + 8 + sz > n) return 1;
-      pos += 8 + sz;
-      continue;
-    }
-    if (magic != 0xfd2fb528u) return 1;
-    pos += 4;
-    if (pos >= n) return 1;
-    uint32_t fhd = src[pos++];
-    uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, has_ck = (fhd >> 2) & 1, did_flag = fhd & 3;
-    if (fhd & 0x08) return 1;
-    if (!single) {
-      if (pos >= n) return 1;
-      pos++;
-    }
-    uint32_t did_bytes = did_flag == 3 ? 4 : did_flag;
-    if (did_bytes) {
-      if (pos + did_bytes > n) return 1;
-      uint32_t did = 0;
-      for (uint32_t i = 0; i < did_bytes; i++) did |= (uint32_t)src[pos + i] << (8 * i);
-      pos += did_bytes;
-      if (did) return 1;
-    }
-    uint32_t fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
-    uint64_t fcs = 0;
-    if (pos + fcs_bytes > n) return 1;
-    for (uint32_t i = 0; i < fcs_bytes; i++) fcs |= (uint64_t)src[pos + i] << (8 * i);
-    if (fcs_bytes == 2) fcs += 256;
-    pos += fcs_bytes;
-    uint64_t frame_start = o.out;
-    ZState z;
-    z.huf_valid = z.ll_valid = z.of_valid = z.ml_valid = 0;
-    z.huf_bits = z.ll_log = z.of_log = z.ml_log = 0;
-    z.rep[0] = 1;
-    z.rep[1] = 4;
-    z.rep[2] = 8;
-    uint32_t last;
-    do {
-      if (pos + 3 > n) return 1;
-      uint32_t bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
-      pos += 3;
-      last = bh & 1;
-      uint32_t bt = (bh >> 1) & 3, bs = bh >> 3;
-      if (bt == 0) {
-        if ((uint64_t)pos + bs > n || o.out + bs > cap) return 1;
-        lz_literal(o, src + pos, bs, lane);
-        pos += bs;
-      } else if (bt == 1) {
-        if (pos + 1 > n || o.out + bs > cap) return 1;
-        lz_fill(o, src[pos], bs, lane);
-        pos += 1;
-      } else if (bt == 2) {
-        if ((uint64_t)pos + bs > n || bs > 128 * 1024) return 1;
-        if (z_block_dev(z, L, src + pos, bs, o, frame_start, cap, scratch, Z, lane PROF_ARG) < 0) return 1;
-        pos += bs;
-      } else {
-        return 1;
-      }
-    } while (!last);
-    if (fcs_bytes && o.out - frame_start != fcs) return 1;
-    if (has_ck) {
-      if (pos + 4 > n) return 1;
-      pos += 4;
-    }
-  }
-  lz_flush(o, lane);
-  *out_len = (uint32_t)o.out;
-  return 0;
 }

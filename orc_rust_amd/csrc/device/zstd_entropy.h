@@ -1,0 +1,439 @@
+// zstd_entropy.h -- Zstandard (RFC 8878) entropy stage: ONE WAVEFRONT PER COMPRESSED BLOCK.
+//
+// Replaces the entropy half of zstd::Decoder (compression.rs:151-159).  The frame and block headers of
+// every chunk are parsed on the host while the stripe is staged (orcgpu_zstd_host.inc): each
+// Compressed_Block becomes a ZBlock that says where its literals section, its sequences section and
+// the table descriptions it depends on live (Treeless literals and Repeat_Mode tables point at the
+// block of the same frame that defined them, so no block waits for another one here).
+//
+// Per block this kernel
+//   1. builds the Huffman table and decodes the literal streams into the block's literal buffer
+//      (16 lanes per stream, self-synchronising restarts: huf_decode_par in zstd_device.h);
+//   2. builds the three FSE tables as 8-byte entries {next state, state bits, extra bits, base value};
+//   3. runs the FSE state machine -- the one serial chain of the format -- with the six bit fields of a
+//      sequence spread over six lanes (offset / match-length / literal-length extra bits, then the three
+//      state updates): ONE LDS lookup, a 3-step DPP prefix sum of the field widths, and one shift pair
+//      per lane extract all fields at once from a wave-uniform 64-bit window.  The bit stream itself is
+//      held in a vector register (lane j = dword j of the current 256-byte segment), so the window is
+//      rebuilt with three v_readlane per sequence and no memory access sits on the chain.
+// It writes {offset value, match length, literal length} per sequence and one status word per block (0 = ok, else a
+// diagnostic code: any nonzero value rejects the chunk); repeat offsets are resolved, and
+// the LZ77 copies executed, by lz_exec_kernel (lz_exec.h), one workgroup per chunk.
+#pragma once
+
+struct ZBlock {
+  const uint8_t* src;    // chunk payload in the staged arena
+  uint8_t* lit_out;      // decoded literals (lit_type >= 2): lit_regen bytes (+ 8 bytes of slack)
+  uint32_t* seq_out;     // nseq x {offset value, match length, literal length}
+  uint32_t chunk;        // index into the chunk table
+  uint32_t content_off, content_end;  // block content inside the payload
+  uint32_t lit_type, lit_streams, lit_hdr, lit_regen, lit_comp;
+  uint32_t nseq, seq_off;    // seq_off: offset of the byte behind Number_of_Sequences (the modes byte)
+  uint32_t huf_off, huf_end; // Huffman tree description: own, or (Treeless) the defining block's; end of that literals section
+  uint32_t tab_off[3];   // per table LL, OF, ML: offset of the modes byte of the block that defines it (own: seq_off)
+  uint32_t tab_end[3];   // ... and the end of that block
+  uint32_t pad[2];
+};
+
+struct ZFse {  // one decoding table cell
+  uint16_t next;   // base of the next state
+  uint8_t nb;      // bits to read for the next state
+  uint8_t add;     // extra bits of the symbol's value
+  uint32_t base;   // base value of the symbol (offset: 1 << code)
+};
+
+struct ZEntLds {
+  union {
+    struct {  // literals phase
+      uint16_t huf[2048];  // sym | nb << 8
+      uint8_t weights[256];
+      FseEnt wt[64];
+    } h;
+    struct {  // sequences phase
+      ZFse ll[512], ml[512], of[256];
+      ZFse zero;           // all-zero cell for the lanes without a field
+    } s;
+  };
+  int16_t norm[256];
+  uint16_t next[256];
+  uint8_t sym[512];        // symbol of every cell while a table is being built
+};
+
+// FSE decoding table with the symbol's extra bits and base value folded into every cell.  which: 0 LL, 1 OF, 2 ML.
+__device__ __forceinline__ int zfse_build(ZFse* t, uint8_t* symtab, const int16_t* norm, int nsym, int log, uint16_t* next, int which, uint32_t lane) {
+  const int size = 1 << log;
+  int bad = 0;
+  if (lane == 0) {
+    int high = size - 1;
+    for (int s = 0; s < nsym; s++) {
+      if (norm[s] == -1) {
+        symtab[high--] = (uint8_t)s;
+        next[s] = 1;
+      } else {
+        next[s] = (uint16_t)norm[s];
+      }
+    }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) {
+      for (int i = 0; i < norm[s]; i++) {
+        symtab[pos] = (uint8_t)s;
+        do {
+          pos = (pos + step) & mask;
+        } while (pos > high);
+      }
+    }
+    if (pos != 0) bad = 1;
+    for (int i = 0; i < size && !bad; i++) {
+      const int s = symtab[i];
+      const uint32_t ns = next[s]++;
+      const int nb = log - z_hibit(ns);
+      ZFse e;
+      e.next = (uint16_t)((ns << nb) - size);
+      e.nb = (uint8_t)nb;
+      if (which == 0) {
+        e.add = Z_LL_BITS[s];
+        e.base = Z_LL_BASE[s];
+      } else if (which == 1) {
+        e.add = (uint8_t)s;
+        e.base = 1u << s;
+      } else {
+        e.add = Z_ML_BITS[s];
+        e.base = Z_ML_BASE[s];
+      }
+      t[i] = e;
+    }
+  }
+  bad = __shfl(bad, 0);
+  wave_sync();
+  return bad;
+}
+
+// One table description (Predefined / RLE / FSE_Compressed) at p: builds it when `build`, returns the bytes it takes or -1.
+__device__ __forceinline__ long zfse_table(ZEntLds& L, ZFse* t, int* log_out, int mode, const uint8_t* p, uint32_t n, int which, bool build,
+                                            uint32_t lane) {
+  const int16_t* def = which == 0 ? Z_LL_DEF : (which == 1 ? Z_OF_DEF : Z_ML_DEF);
+  const int defn = which == 0 ? 36 : (which == 1 ? 29 : 53), deflog = which == 1 ? 5 : 6;
+  const int maxsym = which == 0 ? 36 : (which == 1 ? 32 : 53), maxlog = which == 1 ? 8 : 9;
+  if (mode == 0) {
+    if (build) {
+      for (int i = (int)lane; i < defn; i += 64) L.norm[i] = def[i];
+      wave_sync();
+      if (zfse_build(t, L.sym, L.norm, defn, deflog, L.next, which, lane)) return -1;
+      *log_out = deflog;
+    }
+    return 0;
+  }
+  if (mode == 1) {
+    if (n < 1) return -1;
+    if (build) {
+      const uint32_t s = p[0];
+      if (s >= (uint32_t)maxsym) return -1;  // the state machine meets the symbol at once: code out of range
+      if (lane == 0) {
+        ZFse e;
+        e.next = 0;
+        e.nb = 0;
+        e.add = which == 0 ? Z_LL_BITS[s] : (which == 1 ? (uint8_t)s : Z_ML_BITS[s]);
+        e.base = which == 0 ? Z_LL_BASE[s] : (which == 1 ? 1u << s : Z_ML_BASE[s]);
+        t[0] = e;
+      }
+      wave_sync();
+      *log_out = 0;
+    }
+    return 1;
+  }
+  if (mode == 2) {
+    int nsym = maxsym, log;
+    const long c = fse_read_ncount_dev(p, n, L.norm, &nsym, &log, maxlog, lane);
+    if (c < 0) return -1;
+    if (build) {
+      if (zfse_build(t, L.sym, L.norm, nsym, log, L.next, which, lane)) return -1;
+      *log_out = log;
+    }
+    return c;
+  }
+  return -1;  // Repeat_Mode never reaches here: the host resolved it to the defining block
+}
+
+// The table `which` (0 LL, 1 OF, 2 ML) as described in the block whose modes byte sits at src[moff] (block ends at src[mend]).
+// Returns the bytes the description takes (what the OWN block's parse advances by), or -1.
+__device__ __forceinline__ long zfse_from_block(ZEntLds& L, ZFse* t, int* log_out, const uint8_t* src, uint32_t moff, uint32_t mend, int which,
+                                                 uint32_t lane) {
+  if (moff >= mend) return -1;
+  const uint32_t modes = src[moff];
+  uint32_t p = moff + 1;
+  for (int w = 0; w <= which; w++) {
+    const int mode = (modes >> (6 - 2 * w)) & 3;
+    if (w == which) return zfse_table(L, t, log_out, mode, src + p, mend - p, w, true, lane);
+    if (mode == 3) continue;  // a repeated table takes no bytes
+    const long c = zfse_table(L, t, log_out, mode, src + p, mend - p, w, false, lane);
+    if (c < 0) return -1;
+    p += (uint32_t)c;
+  }
+  return -1;
+}
+
+// Huffman tree description at q (qn bytes available) -> L.h.huf; returns the bytes it takes or -1
+__device__ __forceinline__ long zhuf_tree(ZEntLds& L, const uint8_t* q, uint32_t qn, int* maxbits, uint32_t lane) {
+  if (qn < 1) return -1;
+  int nw;
+  const uint32_t hb = q[0];
+  uint32_t used;
+  if (hb >= 128) {
+    nw = (int)hb - 127;
+    const uint32_t nbytes = (uint32_t)(nw + 1) / 2;
+    if (1 + nbytes > qn) return -1;
+    for (int i = (int)lane; i < nw; i += 64) L.h.weights[i] = (i & 1) ? (q[1 + i / 2] & 15) : (q[1 + i / 2] >> 4);
+    used = 1 + nbytes;
+    wave_sync();
+  } else {
+    if (1 + hb > qn) return -1;
+    int nsym = 256, log;
+    const long c = fse_read_ncount_dev(q + 1, hb, L.norm, &nsym, &log, 6, lane);
+    if (c < 0) return -1;
+    if (fse_build_dev(L.h.wt, L.norm, nsym, log, L.next, lane)) return -1;
+    RBits r;
+    if (!rb_init(r, q + 1 + c, hb - (uint32_t)c)) return -1;
+    uint32_t s1 = (uint32_t)rb_read(r, (uint32_t)log), s2 = (uint32_t)rb_read(r, (uint32_t)log);
+    nw = 0;
+    int fail = 0;
+    for (;;) {
+      if (nw >= 254) {
+        fail = 1;
+        break;
+      }
+      if (lane == 0) L.h.weights[nw] = L.h.wt[s1].sym;
+      nw++;
+      if (r.bits < (long)L.h.wt[s1].nb) {
+        if (lane == 0) L.h.weights[nw] = L.h.wt[s2].sym;
+        nw++;
+        break;
+      }
+      s1 = L.h.wt[s1].base + (uint32_t)rb_read(r, L.h.wt[s1].nb);
+      if (nw >= 254) {
+        fail = 1;
+        break;
+      }
+      if (lane == 0) L.h.weights[nw] = L.h.wt[s2].sym;
+      nw++;
+      if (r.bits < (long)L.h.wt[s2].nb) {
+        if (lane == 0) L.h.weights[nw] = L.h.wt[s1].sym;
+        nw++;
+        break;
+      }
+      s2 = L.h.wt[s2].base + (uint32_t)rb_read(r, L.h.wt[s2].nb);
+    }
+    if (fail) return -1;
+    used = 1 + hb;
+    wave_sync();
+  }
+  if (huf_build_dev(L.h.huf, maxbits, L.h.weights, nw, lane)) return -1;
+  return (long)used;
+}
+
+// ---- the FSE state machine --------------------------------------------------------------------------------
+// Lane roles inside every group of 8 lanes (only lanes 0..7 matter; the others run along harmlessly):
+//   0 offset extra bits   1 match-length extra bits   2 literal-length extra bits   3, 4 nothing
+//   5 literal-length state bits   6 match-length state bits   7 offset state bits
+// = the order in which a sequence's fields follow each other in the backward bit stream (RFC 8878 3.1.1.3.2.1.1),
+// so an inclusive prefix sum of the field widths over the 8 lanes gives every lane the position of its field.
+// Lane k and lane 7-k share a table (row_half_mirror hands the new state from the state lane to the value lane).
+#define ZDPP(x, ctrl) __builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xf, 0xf, false)
+
+// wave-uniform values: tell the compiler (scalar registers, scalar branches)
+__device__ __forceinline__ uint32_t zuni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int zuni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Decodes nseq sequences of one block.  Returns 0, or a nonzero diagnostic code.
+// The backward bit stream q[0 .. qn) is read from its last set bit downwards.  It is held in registers: lane j of `cur`
+// has dword (top - 63 + j) counted from `base` (q rounded down to 4 bytes), `nxt` the segment 48 dwords further down.
+__device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uint32_t qn_, uint32_t nseq_, int ll_log_, int of_log_, int ml_log_,
+                                              uint32_t* seq_out_, uint32_t* dump_, uint32_t lane) {
+  const uint8_t* q = q_;      // (pointers stay what as_global() made them: global address space, vector registers)
+  const uint32_t qn = zuni(qn_), nseq = zuni(nseq_);
+  const int ll_log = zuni(ll_log_), of_log = zuni(of_log_), ml_log = zuni(ml_log_);
+  uint32_t* seq_out = seq_out_;
+  uint32_t* dump = dump_;
+  if (qn == 0) return 21;
+  const uint32_t lastb = zuni((uint32_t)q[qn - 1]);
+  if (lastb == 0) return 21;
+  const uint32_t qo = zuni((uint32_t)(reinterpret_cast<uintptr_t>(q) & 3));
+  const uint8_t* base = q - qo;
+  const int nbytes = (int)(qn + qo);           // bytes from base to the end of the stream
+  const int hb = 31 - __builtin_clz(lastb);
+  int P = (int)(qn - 1) * 8 + hb;              // unread bits; bit b of the stream is bit g0 + b counted from base
+  const int g0 = 8 * (int)qo;
+  int top = (g0 + P) >> 5;                     // dword held by lane 63 of `cur`
+  auto seg_load = [&](int t) -> uint32_t {
+    const int d = t - 63 + (int)lane;
+    // dwords below the stream (d < 0) or wholly behind its end are never looked at: zero
+    return (d >= 0 && d * 4 < nbytes + 4) ? *reinterpret_cast<const uint32_t*>(base + (long)d * 4) : 0u;
+  };
+  uint32_t cur = seg_load(top), nxt = seg_load(top - 48);
+
+  const uint32_t r = lane < 8 ? lane : 3;  // lanes 8..63 have no field: they look at the all-zero cell like lanes 3 and 4
+  const bool is_x = r < 3;
+  // table of this lane's role and where its field width sits in the cell's first word
+  ZFse* tb = (r == 0 || r == 7) ? L.s.of : ((r == 1 || r == 6) ? L.s.ml : ((r == 2 || r == 5) ? L.s.ll : &L.s.zero));
+  const uint32_t sh = is_x ? 24u : 16u;
+  const bool has_tab = r != 3 && r != 4;
+
+  // 64 unread bits below position p (wave uniform), left aligned (bit 63 = stream bit p - 1); bits below the stream read as zero
+  auto window = [&](int p) -> uint64_t {
+    if (p <= 0) return 0;
+    const int gt = g0 + p - 1;            // top unread bit, counted from base
+    int rel = (gt >> 5) - (top - 63);     // lane of `cur` that holds it
+    if (rel < 16) {                       // keep three dwords (rel, rel-1, rel-2) inside the segment
+      cur = nxt;
+      top -= 48;
+      rel += 48;
+      nxt = seg_load(top - 48);
+    }
+    const uint32_t t = (uint32_t)(gt & 31) + 1;  // 1..32 bits of the top dword are unread
+    const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)cur, rel);
+    const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)cur, rel - 1);
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, rel - 2);
+    const uint64_t hi = (((uint64_t)d2 << 32) | d1) >> t;  // low 32 bits: window bits 63..32
+    const uint64_t lo = (((uint64_t)d1 << 32) | d0) >> t;
+    uint64_t w = (hi << 32) | (lo & 0xffffffffu);
+    if (p < 64) w &= ~0ull << (64 - p);  // nothing below bit 0 of the stream
+    return w;
+  };
+
+  // initial states: LL, OF, ML (RFC 8878 3.1.1.3.2.1.1)
+  uint32_t state;
+  {
+    uint64_t w = window(P);
+    const uint32_t sl = ll_log ? (uint32_t)(w >> (64 - ll_log)) : 0;
+    w <<= ll_log;
+    const uint32_t so = of_log ? (uint32_t)(w >> (64 - of_log)) : 0;
+    w <<= of_log;
+    const uint32_t sm = ml_log ? (uint32_t)(w >> (64 - ml_log)) : 0;
+    P -= ll_log + of_log + ml_log;
+    state = (r == 0 || r == 7) ? so : ((r == 1 || r == 6) ? sm : ((r == 2 || r == 5) ? sl : 0));
+  }
+  if (P < 0) return 22;
+
+  uint32_t* my_out = lane < 3 ? seq_out + lane : dump + lane;  // lanes 0..2 write {offset value, match length, literal length}
+  const uint32_t out_step = lane < 3 ? 3u : 0u;
+  for (uint32_t i = 0; i < nseq; i++) {
+    const bool last = i + 1 == nseq;
+    const uint64_t w = window(P);
+    const ZFse* cell = tb + (has_tab ? state : 0);
+    const uint32_t e0 = reinterpret_cast<const uint32_t*>(cell)[0];
+    const uint32_t e1 = reinterpret_cast<const uint32_t*>(cell)[1];
+    uint32_t cnt = (e0 >> sh) & 0xffu;
+    if (last && !is_x) cnt = 0;  // no state update behind the last sequence
+    uint32_t incl = cnt;
+    incl += (uint32_t)ZDPP(incl, 0x111);  // row_shr:1
+    incl += (uint32_t)ZDPP(incl, 0x112);  // row_shr:2
+    incl += (uint32_t)ZDPP(incl, 0x114);  // row_shr:4
+    const int total = __builtin_amdgcn_readlane((int)incl, 7);
+    uint32_t val;
+    if (total <= 64) {
+      const uint64_t x = w << (incl - cnt);
+      val = cnt ? (uint32_t)(x >> (64 - cnt)) : 0u;
+    } else {
+      // more than 64 bits in one sequence (only with offsets / lengths near the format's limits): every lane
+      // fetches its own field bit by bit from memory
+      val = 0;
+      const int topbit = P - (int)(incl - cnt);
+      for (uint32_t k = 0; k < cnt; k++) {
+        const int bi = topbit - 1 - (int)k;
+        val = (val << 1) | (bi >= 0 ? (uint32_t)(q[bi >> 3] >> (bi & 7)) & 1u : 0u);
+      }
+    }
+    const uint32_t nv = (is_x ? e1 : (e0 & 0xffffu)) + val;
+    *my_out = nv;
+    my_out += out_step;
+    const uint32_t mirrored = (uint32_t)ZDPP(nv, 0x141);  // row_half_mirror: lane k <- lane 7 - k
+    state = is_x ? mirrored : nv;
+    P -= total;
+    if (P < 0) return 23;  // the stream ran dry
+  }
+  return P == 0 ? 0 : 24;  // every bit must be used
+}
+
+// ---- the kernel -------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBlock* __restrict__ blocks, uint32_t n_blocks, uint32_t* dump_words,
+                                                                     uint32_t* __restrict__ status_out) {
+  __shared__ ZEntLds L;
+  const uint32_t b = blockIdx.x;
+  if (b >= n_blocks) return;
+  const uint32_t lane = threadIdx.x;
+  ZBlock B = blocks[b];
+  const uint8_t* src = as_global(B.src);
+  uint8_t* lit_out = (uint8_t*)as_global((void*)B.lit_out);
+  uint32_t* seq_out = (uint32_t*)as_global((void*)B.seq_out);
+  uint32_t* dump = (uint32_t*)as_global((void*)dump_words) + (size_t)(b & 1023u) * 64;
+  int st = 0;
+  // ---- literals ----
+  if (B.lit_type >= 2) {
+    int mb = 0;
+    const uint8_t* q = src + B.content_off + B.lit_hdr;
+    uint32_t qn = B.lit_comp;
+    if (B.lit_type == 2) {
+      const long used = zhuf_tree(L, q, qn, &mb, lane);
+      if (used < 0) st = 11;
+      else {
+        q += used;
+        qn -= (uint32_t)used;
+      }
+    } else {
+      // Treeless: the table of the block that last described one (same frame)
+      if (zhuf_tree(L, src + B.huf_off, B.huf_end - B.huf_off, &mb, lane) < 0) st = 12;
+    }
+    if (!st) {
+      int bad = 0;
+      const uint32_t regen = B.lit_regen;
+      if (B.lit_streams == 1) {
+        bad = huf_decode_par(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true);
+      } else {
+        if (qn < 6) st = 13;
+        else {
+          const uint32_t s1 = q[0] | (q[1] << 8), s2 = q[2] | (q[3] << 8), s3 = q[4] | (q[5] << 8);
+          if (6 + s1 + s2 + s3 > qn) st = 14;
+          else {
+            const uint32_t s4 = qn - 6 - s1 - s2 - s3;
+            const uint32_t seg = (regen + 3) / 4;
+            if (seg * 3 > regen) st = 15;
+            else {
+              const uint8_t* bp = q + 6;
+              const uint32_t k = lane >> 4;  // stream of this lane (16 lanes each)
+              const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
+              const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
+              const uint32_t on = k < 3 ? seg : regen - 3 * seg;
+              bad = huf_decode_par(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true);
+            }
+          }
+        }
+      }
+      if (!st && __ballot(bad != 0)) st = 16;
+    }
+    wave_sync();
+  }
+  // ---- sequences ----
+  if (!st && B.nseq) {
+    int ll_log = 0, of_log = 0, ml_log = 0;
+    uint32_t p = B.seq_off + 1;  // own descriptions follow the modes byte
+    const uint32_t end = B.content_end;
+    if (lane == 0) L.s.zero = ZFse{0, 0, 0, 0};
+    for (int w = 0; w < 3 && !st; w++) {
+      ZFse* t = w == 0 ? L.s.ll : (w == 1 ? L.s.of : L.s.ml);
+      int* lg = w == 0 ? &ll_log : (w == 1 ? &of_log : &ml_log);
+      if (B.tab_off[w] == B.seq_off) {
+        const int mode = (src[B.seq_off] >> (6 - 2 * w)) & 3;
+        const long c = p <= end ? zfse_table(L, t, lg, mode, src + p, end - p, w, true, lane) : -1;
+        if (c < 0) st = 17 + w;
+        else p += (uint32_t)c;
+      } else {
+        if (zfse_from_block(L, t, lg, src, B.tab_off[w], B.tab_end[w], w, lane) < 0) st = 17 + w;
+      }
+    }
+    wave_sync();
+    if (!st) {
+      if (p > end) st = 20;
+      else st = zfse_sequences(L, src + p, end - p, B.nseq, ll_log, of_log, ml_log, seq_out, dump, lane);
+    }
+  }
+  if (lane == 0) status_out[b] = (uint32_t)st;
+}

@@ -104,19 +104,26 @@ struct ChunkInfo {
   uint64_t src_off;  // offset of the chunk payload inside the stream
   uint32_t len;
   uint32_t original;
-  uint32_t plain_cap;  // bytes the chunk can expand to (exact for original and Snappy chunks)
+  uint32_t plain_cap;  // bytes the chunk can expand to (exact for original and Snappy chunks, and for Zstandard frames that state their size)
+  int32_t zparse = -1; // Zstandard: index into StagedStream::zchunks
 };
 
+
+}  // namespace
+
+#include "orcgpu_zstd_host.inc"
+
+namespace {
 struct StagedStream {
   uint32_t column_id;
   int32_t kind;
   uint64_t off;  // offset inside the staged arena
   uint64_t len;
   std::vector<ChunkInfo> chunks;  // only for compressed stripes
+  std::vector<ZChunkParse> zchunks;  // Zstandard: frame / block headers of every compressed chunk
   bool framing_error = false;     // truncated chunk header / payload (compression.rs:253-261 panics)
   uint64_t framed_len = 0;        // bytes covered by well-formed chunks
 };
-
 }  // namespace
 
 struct orcgpu_ctx {
@@ -212,6 +219,65 @@ void set_err(orcgpu_ctx* c, const char* fmt, ...) {
       return ORCGPU_HIP_ERROR;                                                          \
     }                                                                                   \
   } while (0)
+
+// Chunk framing scan on the host while the bytes are at hand (compression.rs:113-123, :244-267): one ChunkInfo per
+// 3-byte header; Snappy blocks and Zstandard frames also say how large their output is.
+void scan_chunks(const uint8_t* ptr, uint64_t len_total, int compression, uint64_t block_size, StagedStream& st) {
+  uint64_t p = 0;
+  while (p < len_total) {
+    if (p + 3 > len_total) {
+      st.framing_error = true;
+      break;
+    }
+    uint32_t h = (uint32_t)ptr[p] | ((uint32_t)ptr[p + 1] << 8) | ((uint32_t)ptr[p + 2] << 16);
+    uint32_t len = h >> 1;
+    if (p + 3 + len > len_total) {
+      st.framing_error = true;
+      break;
+    }
+    uint32_t cap = (uint32_t)block_size;
+    if (h & 1) {
+      cap = len;
+    } else if (compression == ORCGPU_COMP_SNAPPY) {
+      // Snappy blocks start with their uncompressed length (snap::raw::decompress_len, compression.rs:163-164)
+      uint64_t u = 0;
+      int shift = 0;
+      for (uint32_t k = 0; k < len && k < 5; k++) {
+        uint8_t c = ptr[p + 3 + k];
+        u |= (uint64_t)(c & 0x7f) << shift;
+        shift += 7;
+        if (!(c & 0x80)) break;
+      }
+      if (u <= (1ull << 31)) cap = (uint32_t)u;
+    }
+    ChunkInfo ci{p + 3, len, h & 1, cap, -1};
+    if (!(h & 1) && compression == ORCGPU_COMP_ZSTD) {
+      // frame and block headers (RFC 8878 3.1.1): what lets the device decode every block on its own
+      ZChunkParse zp;
+      zstd_parse_chunk(ptr + p + 3, len, zp);
+      // the zstd crate grows its output as needed; the oracle gives it max(block size, 4 MiB)
+      const uint64_t limit = std::max<uint64_t>(block_size, 1u << 22);
+      const uint64_t bound = zp.size_known ? zp.plain_size : limit;
+      uint64_t need_seq = 0, need_lit = 0;
+      for (auto& it : zp.items) {
+        need_seq += it.kind == 2 ? 3ull * it.nseq : 0;  // a sequence yields at least 3 bytes
+        need_lit += it.kind == 2 ? it.lit_regen : 0;    // every literal is output
+      }
+      if (!zp.bad && (bound > limit || need_seq > bound || need_lit > bound)) zp.bad = true;
+      if (zp.bad) {
+        zp.items.clear();
+        ci.plain_cap = 0;
+      } else if (zp.size_known) {
+        ci.plain_cap = (uint32_t)zp.plain_size;
+      }
+      ci.zparse = (int32_t)st.zchunks.size();
+      st.zchunks.push_back(std::move(zp));
+    }
+    st.chunks.push_back(ci);
+    p += 3 + (uint64_t)len;
+  }
+  st.framed_len = p;
+}
 
 uint32_t type_width(int t) {
   switch (t) {
@@ -376,40 +442,7 @@ int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_sta
     st.len = in.len;
     st.off = b.take(in.len + ORC_PAD);
     s->stream_bytes += in.len;
-    if (d->compression != ORCGPU_COMP_NONE) {
-      // chunk framing scan on the host while the bytes are at hand (compression.rs:113-123, :244-267)
-      uint64_t p = 0;
-      while (p < in.len) {
-        if (p + 3 > in.len) {
-          st.framing_error = true;
-          break;
-        }
-        uint32_t h = (uint32_t)in.ptr[p] | ((uint32_t)in.ptr[p + 1] << 8) | ((uint32_t)in.ptr[p + 2] << 16);
-        uint32_t len = h >> 1;
-        if (p + 3 + len > in.len) {
-          st.framing_error = true;
-          break;
-        }
-        uint32_t cap = (uint32_t)s->desc.block_size;
-        if (h & 1) {
-          cap = len;
-        } else if (d->compression == ORCGPU_COMP_SNAPPY) {
-          // Snappy blocks start with their uncompressed length (snap::raw::decompress_len, compression.rs:163-164)
-          uint64_t u = 0;
-          int shift = 0;
-          for (uint32_t k = 0; k < len && k < 5; k++) {
-            uint8_t c = in.ptr[p + 3 + k];
-            u |= (uint64_t)(c & 0x7f) << shift;
-            shift += 7;
-            if (!(c & 0x80)) break;
-          }
-          if (u <= (1ull << 31)) cap = (uint32_t)u;
-        }
-        st.chunks.push_back(ChunkInfo{p + 3, len, h & 1, cap});
-        p += 3 + (uint64_t)len;
-      }
-      st.framed_len = p;
-    }
+    if (d->compression != ORCGPU_COMP_NONE) scan_chunks(in.ptr, in.len, d->compression, s->desc.block_size, st);
     s->streams.push_back(std::move(st));
   }
   s->dev_bytes = align_up(b.off + ORC_PAD);
