@@ -4,7 +4,10 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SO = os.path.join(CSRC, "liborcgpu.so")
+# ORCGPU_CFLAGS: extra compiler flags for development builds (e.g. -DORC_PROF: per-phase device timing, printed with
+# ORCGPU_DEBUG=1); such a build goes to its own file so that the product library is never replaced by it.
+_EXTRA = os.environ.get("ORCGPU_CFLAGS", "").split()
+SO = os.path.join(CSRC, "liborcgpu.so" if not _EXTRA else "liborcgpu_dev.so")
 
 
 def _sources():
@@ -35,7 +38,7 @@ def build(force=False):
             if force or not _fresh(srcs):
                 hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
                 tmp = SO + ".tmp.%d" % os.getpid()
-                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", tmp, os.path.join(CSRC, "orcgpu.hip")]
+                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + _EXTRA + ["-o", tmp, os.path.join(CSRC, "orcgpu.hip")]
                 subprocess.check_call(cmd, cwd=CSRC)
                 os.replace(tmp, SO)
         finally:

@@ -675,7 +675,7 @@ __device__ __forceinline__ void decompress_chunks_body(ChunkDesc* chunks, uint32
     bad = 1;  // unknown compression kind
   }
   PROF_MARK(5);
-  PROF_END();
+  PROF_END_AT(48);
   if (lane == 0) {
     chunks[c].out_len = bad ? 0 : out_len;
     chunks[c].status = bad ? ORC_E_CODEC : 0;

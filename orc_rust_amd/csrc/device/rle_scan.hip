@@ -27,7 +27,7 @@
 
 // Phase timing for development builds (-DORC_PROF): per-phase sum / max of wavefront wall-clock ticks (10 ns).
 #ifdef ORC_PROF
-__device__ unsigned long long g_prof[48];
+__device__ unsigned long long g_prof[176];  // [0, 32): walk kernels, [32, 48): counters, [48, 80): decompressors, [80, 112): lz_exec, [112, 144): zstd_entropy, [144, 176): counters
 struct Prof {
   unsigned long long t;
   unsigned long long acc[16];
@@ -52,6 +52,17 @@ struct Prof {
         }                                                       \
     }                                                           \
   } while (0)
+#define PROF_END_AT(base)                                       \
+  do {                                                          \
+    if ((threadIdx.x & 63) == 0) {                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++)         \
+        if (prof.acc[i_]) {                                     \
+          atomicAdd(&g_prof[(base) + 2 * i_], prof.acc[i_]);    \
+          atomicMax(&g_prof[(base) + 2 * i_ + 1], prof.acc[i_]);\
+        }                                                       \
+    }                                                           \
+  } while (0)
+#define PROF_COUNT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[144 + (i)], (unsigned long long)(v)); } while (0)
 #define PROF_ARG , prof
 #define PROF_PARM , Prof& prof
 #else
@@ -60,6 +71,8 @@ struct Prof {
 #define PROF_MARK(i)
 #define PROF_BEGIN()
 #define PROF_END()
+#define PROF_END_AT(base)
+#define PROF_COUNT(i, v)
 #endif
 
 __device__ __forceinline__ void wave_sync_scan() {

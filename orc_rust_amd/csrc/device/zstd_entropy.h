@@ -52,6 +52,7 @@ struct ZEntLds {
     struct {  // sequences phase
       ZFse ll[512], ml[512], of[256];
       ZFse zero;           // all-zero cell for the lanes without a field
+      uint32_t seqbuf[64 * 3 + 64];  // 64 decoded sequences waiting for their coalesced store (+ a sink for the idle lanes)
     } s;
   };
   int16_t norm[256];
@@ -268,7 +269,9 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
     // dwords below the stream (d < 0) or wholly behind its end are never looked at: zero
     return (d >= 0 && d * 4 < nbytes + 4) ? *reinterpret_cast<const uint32_t*>(base + (long)d * 4) : 0u;
   };
-  uint32_t cur = seg_load(top), nxt = seg_load(top - 48);
+  // (no load stays in flight across iterations: vmcnt counts loads and stores alike on this target, so waiting for a
+  // prefetched segment would also wait for every store issued since)
+  uint32_t cur = seg_load(top);
 
   const uint32_t r = lane < 8 ? lane : 3;  // lanes 8..63 have no field: they look at the all-zero cell like lanes 3 and 4
   const bool is_x = r < 3;
@@ -282,11 +285,10 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
     if (p <= 0) return 0;
     const int gt = g0 + p - 1;            // top unread bit, counted from base
     int rel = (gt >> 5) - (top - 63);     // lane of `cur` that holds it
-    if (rel < 16) {                       // keep three dwords (rel, rel-1, rel-2) inside the segment
-      cur = nxt;
-      top -= 48;
-      rel += 48;
-      nxt = seg_load(top - 48);
+    if (rel < 3) {                        // keep three dwords (rel, rel-1, rel-2) inside the segment: next 61 dwords down
+      top -= 61;
+      rel += 61;
+      cur = seg_load(top);
     }
     const uint32_t t = (uint32_t)(gt & 31) + 1;  // 1..32 bits of the top dword are unread
     const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)cur, rel);
@@ -313,9 +315,77 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
   }
   if (P < 0) return 22;
 
-  uint32_t* my_out = lane < 3 ? seq_out + lane : dump + lane;  // lanes 0..2 write {offset value, match length, literal length}
-  const uint32_t out_step = lane < 3 ? 3u : 0u;
-  for (uint32_t i = 0; i < nseq; i++) {
+  // lanes 0..2 file {offset value, match length, literal length} in LDS; every 64 sequences leave with three coalesced stores
+  (void)dump;
+  uint32_t* const sb = L.s.seqbuf;
+  const uint32_t slot0 = lane < 3 ? lane : 192u + lane;
+  const uint32_t slot_step = lane < 3 ? 3u : 0u;
+  auto flush = [&](uint32_t first, uint32_t count) {  // sequences [first, first + count) are in seqbuf
+    wave_sync();
+    uint32_t* o = seq_out + 3ull * first;
+    for (uint32_t k = lane; k < 3 * count; k += 64) o[k] = sb[k];
+    wave_sync();
+  };
+  const uint32_t tbase = (uint32_t)(uintptr_t)tb;  // LDS byte address of this lane's table
+  uint32_t i = 0;
+  // ---- groups of 64 sequences far from the end of the stream: no bit below the stream can be touched (a sequence takes
+  // at most 89 bits), none of them is the block's last sequence ----
+  while (nseq - i > 64 && P >= 64 * 89 + 128) {
+    int G = g0 + P - 1;           // top unread bit, counted from base
+    int segbase = top - 63;       // dword held by lane 0 of `cur`
+    uint32_t slot = slot0;
+    for (uint32_t k = 0; k < 64; k++) {
+      int rel = (G >> 5) - segbase;
+      if (rel < 2) {              // keep three dwords (rel, rel-1, rel-2) inside the segment
+        segbase -= 61;
+        rel += 61;
+        cur = seg_load(segbase + 63);
+      }
+      const uint32_t t = (uint32_t)(G & 31) + 1;
+      const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)cur, rel);
+      const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)cur, rel - 1);
+      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, rel - 2);
+      const uint64_t hi = (((uint64_t)d2 << 32) | d1) >> t;
+      const uint64_t lo = (((uint64_t)d1 << 32) | d0) >> t;
+      const uint64_t w = (hi << 32) | (lo & 0xffffffffu);
+      const uint32_t addr = tbase + (has_tab ? state << 3 : 0u);
+      const uint64_t e = *reinterpret_cast<const __attribute__((address_space(3))) uint64_t*>((uintptr_t)addr);
+      const uint32_t e0 = (uint32_t)e, e1 = (uint32_t)(e >> 32);
+      const uint32_t cnt = (e0 >> sh) & 0xffu;
+      uint32_t incl = cnt;
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);
+      const int total = __builtin_amdgcn_readlane((int)incl, 7);
+      uint32_t val;
+      if (__builtin_expect(total <= 64, 1)) {
+        // the field's bits are the top `cnt` bits of (w << excl): via the high word, cnt <= 31
+        const uint32_t hw = (uint32_t)((w << (incl - cnt)) >> 32);
+        val = (hw >> 1) >> (31u - cnt);
+      } else {
+        val = 0;
+        const int topbit = G - g0 + 1 - (int)(incl - cnt);
+        for (uint32_t b = 0; b < cnt; b++) {
+          const int bi = topbit - 1 - (int)b;
+          val = (val << 1) | (bi >= 0 ? (uint32_t)(q[bi >> 3] >> (bi & 7)) & 1u : 0u);
+        }
+      }
+      const uint32_t nv = (is_x ? e1 : (e0 & 0xffffu)) + val;
+      sb[slot] = nv;
+      slot += slot_step;
+      const uint32_t mirrored = (uint32_t)ZDPP(nv, 0x141);  // row_half_mirror: lane k <- lane 7 - k
+      state = is_x ? mirrored : nv;
+      G -= total;
+    }
+    P = G - g0 + 1;
+    top = segbase + 63;
+    flush(i, 64u);
+    i += 64;
+  }
+  // ---- the rest, with every check ----
+  uint32_t slot = slot0;
+  const uint32_t first_rest = i;
+  for (; i < nseq; i++) {
     const bool last = i + 1 == nseq;
     const uint64_t w = window(P);
     const ZFse* cell = tb + (has_tab ? state : 0);
@@ -343,13 +413,18 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
       }
     }
     const uint32_t nv = (is_x ? e1 : (e0 & 0xffffu)) + val;
-    *my_out = nv;
-    my_out += out_step;
+    sb[slot] = nv;
+    slot += slot_step;
+    if (((i - first_rest) & 63u) == 63u) {
+      flush(i - 63u, 64u);
+      slot = slot0;
+    }
     const uint32_t mirrored = (uint32_t)ZDPP(nv, 0x141);  // row_half_mirror: lane k <- lane 7 - k
     state = is_x ? mirrored : nv;
     P -= total;
     if (P < 0) return 23;  // the stream ran dry
   }
+  if ((nseq - first_rest) & 63u) flush(first_rest + ((nseq - first_rest) & ~63u), (nseq - first_rest) & 63u);
   return P == 0 ? 0 : 24;  // every bit must be used
 }
 
@@ -360,6 +435,7 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
   const uint32_t b = blockIdx.x;
   if (b >= n_blocks) return;
   const uint32_t lane = threadIdx.x;
+  PROF_BEGIN();
   ZBlock B = blocks[b];
   const uint8_t* src = as_global(B.src);
   uint8_t* lit_out = (uint8_t*)as_global((void*)B.lit_out);
@@ -369,6 +445,7 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
   // ---- literals ----
   if (B.lit_type >= 2) {
     int mb = 0;
+    PROF_MARK(0);
     const uint8_t* q = src + B.content_off + B.lit_hdr;
     uint32_t qn = B.lit_comp;
     if (B.lit_type == 2) {
@@ -382,6 +459,7 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
       // Treeless: the table of the block that last described one (same frame)
       if (zhuf_tree(L, src + B.huf_off, B.huf_end - B.huf_off, &mb, lane) < 0) st = 12;
     }
+    PROF_MARK(1);
     if (!st) {
       int bad = 0;
       const uint32_t regen = B.lit_regen;
@@ -410,6 +488,7 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
       if (!st && __ballot(bad != 0)) st = 16;
     }
     wave_sync();
+    PROF_MARK(2);
   }
   // ---- sequences ----
   if (!st && B.nseq) {
@@ -430,10 +509,14 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
       }
     }
     wave_sync();
+    PROF_MARK(3);
     if (!st) {
       if (p > end) st = 20;
       else st = zfse_sequences(L, src + p, end - p, B.nseq, ll_log, of_log, ml_log, seq_out, dump, lane);
     }
   }
+  PROF_MARK(4);
+  PROF_COUNT(4, B.nseq);
+  PROF_END_AT(112);
   if (lane == 0) status_out[b] = (uint32_t)st;
 }
