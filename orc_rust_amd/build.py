@@ -7,7 +7,7 @@ CSRC = os.path.join(HERE, "csrc")
 # ORCGPU_CFLAGS: extra compiler flags for development builds (e.g. -DORC_PROF: per-phase device timing, printed with
 # ORCGPU_DEBUG=1); such a build goes to its own file so that the product library is never replaced by it.
 _EXTRA = os.environ.get("ORCGPU_CFLAGS", "").split()
-SO = os.path.join(CSRC, "liborcgpu.so" if not _EXTRA else "liborcgpu_dev.so")
+SO = os.path.join(CSRC, "liborcgpu.so" if not _EXTRA else "liborcgpu_dev%s.so" % os.environ.get("ORCGPU_DEV_TAG", ""))
 
 
 def _sources():

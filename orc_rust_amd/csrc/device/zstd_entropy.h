@@ -53,6 +53,7 @@ struct ZEntLds {
       ZFse ll[512], ml[512], of[256];
       ZFse zero;           // all-zero cell for the lanes without a field
       uint32_t seqbuf[64 * 3 + 64];  // 64 decoded sequences waiting for their coalesced store (+ a sink for the idle lanes)
+      __attribute__((aligned(8))) uint8_t bits[2048 + 16];  // the piece of the bit stream the state machine is working in
     } s;
   };
   int16_t norm[256];
@@ -329,58 +330,74 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
   const uint32_t tbase = (uint32_t)(uintptr_t)tb;  // LDS byte address of this lane's table
   uint32_t i = 0;
   // ---- groups of 64 sequences far from the end of the stream: no bit below the stream can be touched (a sequence takes
-  // at most 89 bits), none of them is the block's last sequence ----
-  while (nseq - i > 64 && P >= 64 * 89 + 128) {
-    int G = g0 + P - 1;           // top unread bit, counted from base
-    int segbase = top - 63;       // dword held by lane 0 of `cur`
-    uint32_t slot = slot0;
-    for (uint32_t k = 0; k < 64; k++) {
-      int rel = (G >> 5) - segbase;
-      if (rel < 2) {              // keep three dwords (rel, rel-1, rel-2) inside the segment
-        segbase -= 61;
-        rel += 61;
-        cur = seg_load(segbase + 63);
-      }
-      const uint32_t t = (uint32_t)(G & 31) + 1;
-      const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)cur, rel);
-      const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)cur, rel - 1);
-      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, rel - 2);
-      const uint64_t hi = (((uint64_t)d2 << 32) | d1) >> t;
-      const uint64_t lo = (((uint64_t)d1 << 32) | d0) >> t;
-      const uint64_t w = (hi << 32) | (lo & 0xffffffffu);
-      const uint32_t addr = tbase + (has_tab ? state << 3 : 0u);
-      const uint64_t e = *reinterpret_cast<const __attribute__((address_space(3))) uint64_t*>((uintptr_t)addr);
-      const uint32_t e0 = (uint32_t)e, e1 = (uint32_t)(e >> 32);
-      const uint32_t cnt = (e0 >> sh) & 0xffu;
-      uint32_t incl = cnt;
-      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);
-      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);
-      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);
-      const int total = __builtin_amdgcn_readlane((int)incl, 7);
-      uint32_t val;
-      if (__builtin_expect(total <= 64, 1)) {
-        // the field's bits are the top `cnt` bits of (w << excl): via the high word, cnt <= 31
-        const uint32_t hw = (uint32_t)((w << (incl - cnt)) >> 32);
-        val = (hw >> 1) >> (31u - cnt);
-      } else {
-        val = 0;
-        const int topbit = G - g0 + 1 - (int)(incl - cnt);
-        for (uint32_t b = 0; b < cnt; b++) {
-          const int bi = topbit - 1 - (int)b;
-          val = (val << 1) | (bi >= 0 ? (uint32_t)(q[bi >> 3] >> (bi & 7)) & 1u : 0u);
+  // at most 89 bits), none of them is the block's last sequence.  The bit stream is staged in LDS 2 KiB at a time; per
+  // sequence ONE 8-byte word that holds the next 57..64 unread bits is fetched together with the table cells (one LDS
+  // latency), and every lane cuts its field out of it. ----
+  if (nseq > 64 && P >= 64 * 89 + 128) {
+    int T = P;                    // unread bits (stream bit T - 1 is the next one)
+    int origin = 0x7fffffff;      // stream byte held by bits[0] (nothing staged yet)
+    const uint32_t bits_lds = (uint32_t)(uintptr_t)L.s.bits;
+    while (nseq - i > 64 && T >= 64 * 89 + 128) {
+      // the stage must hold the words of the next 64 sequences: bytes [(T - 64 * 89 - 57) / 8, T / 8]
+      if ((T - 64 * 89 - 64) >> 3 < origin) {
+        wave_sync();
+        origin = ((T - 57) >> 3) + 8 - 2048;
+        if (origin < 0) origin = 0;
+        for (uint32_t o = lane * 8; o < 2048 + 8; o += 512) {
+          const uint64_t v = ld_u64(q + origin + o);  // (at most 15 bytes behind the stream: slack of the staged arena)
+          __builtin_memcpy(L.s.bits + o, &v, 8);
         }
+        wave_sync();
       }
-      const uint32_t nv = (is_x ? e1 : (e0 & 0xffffu)) + val;
-      sb[slot] = nv;
-      slot += slot_step;
-      const uint32_t mirrored = (uint32_t)ZDPP(nv, 0x141);  // row_half_mirror: lane k <- lane 7 - k
-      state = is_x ? mirrored : nv;
-      G -= total;
+      uint32_t slot = slot0;
+      uint32_t k = 0;
+      bool wide = false;  // a sequence of more than 57 bits came up: it is decoded by the careful loop below
+      for (; k < 64; k++) {
+        const int B = (T - 57) >> 3;       // the word q[B .. B + 8) holds stream bits [8B, 8B + 64): at least 57 unread ones
+        const uint32_t waddr = bits_lds + (uint32_t)(B - origin);
+        const uint32_t addr = tbase + (has_tab ? state << 3 : 0u);
+        const uint64_t e = *reinterpret_cast<const __attribute__((address_space(3))) uint64_t*>((uintptr_t)addr);
+#if defined(ZEXP) && ZEXP == 2
+        uint64_t word = (uint64_t)waddr * 0x9e3779b97f4a7c15ull;
+#else
+        uint64_t word = *reinterpret_cast<const __attribute__((address_space(3))) uint64_t*>((uintptr_t)waddr);
+#endif
+        uint32_t e0 = (uint32_t)e, e1 = (uint32_t)(e >> 32);
+        asm volatile("" : "+v"(e0), "+v"(e1), "+v"(word));  // both reads are in flight together: ONE LDS latency per sequence
+        const uint32_t cnt = (e0 >> sh) & 0xffu;
+        // inclusive prefix sum of the field widths over lanes 0..7: fused DPP adds (two wait states between a VALU write
+        // and a DPP read of the same register)
+        uint32_t incl = cnt;
+        asm volatile(
+            "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 0"
+            : "+v"(incl));
+        const int total = __builtin_amdgcn_readlane((int)incl, 7);
+        if (__builtin_expect(total > 57, 0)) {
+          wide = true;
+          break;
+        }
+        // the field's lowest bit is stream bit T - incl, i.e. bit (T - 8B) - incl of the word
+        const uint32_t x = (uint32_t)(word >> ((uint32_t)(T - 8 * B) - incl));
+        const uint32_t val = x & ~(~0u << cnt);  // cnt <= 31
+        const uint32_t nv = (is_x ? e1 : (e0 & 0xffffu)) + val;
+        sb[slot] = nv;
+        slot += slot_step;
+        const uint32_t mirrored = (uint32_t)ZDPP(nv, 0x141);  // row_half_mirror: lane k <- lane 7 - k
+        state = is_x ? mirrored : nv;
+        T -= total;
+      }
+#if !defined(ZEXP) || ZEXP != 1
+      if (k) flush(i, k);
+#endif
+      i += k;
+      if (wide) break;
     }
-    P = G - g0 + 1;
-    top = segbase + 63;
-    flush(i, 64u);
-    i += 64;
+    P = T;
+    top = (g0 + P) >> 5;
+    cur = seg_load(top);
   }
   // ---- the rest, with every check ----
   uint32_t slot = slot0;
