@@ -62,53 +62,60 @@ struct ZEntLds {
 };
 
 // FSE decoding table with the symbol's extra bits and base value folded into every cell.  which: 0 LL, 1 OF, 2 ML.
+// Lane s works for symbol s (at most 53 symbols): the cells are spread over the table in closed form when no symbol has
+// the "less than one" probability (else by lane 0, cell after cell), then every lane walks the table once and numbers
+// the cells of its own symbol in ascending order -- the order that fixes each cell's next-state base (RFC 8878 4.1.1).
 __device__ __forceinline__ int zfse_build(ZFse* t, uint8_t* symtab, const int16_t* norm, int nsym, int log, uint16_t* next, int which, uint32_t lane) {
   const int size = 1 << log;
+  const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+  const int cnt = (int)lane < nsym ? (int)norm[lane] : 0;
+  const bool lowprob = __ballot(cnt == -1) != 0;
   int bad = 0;
-  if (lane == 0) {
-    int high = size - 1;
-    for (int s = 0; s < nsym; s++) {
-      if (norm[s] == -1) {
-        symtab[high--] = (uint8_t)s;
-        next[s] = 1;
-      } else {
-        next[s] = (uint16_t)norm[s];
+  if (!lowprob) {
+    const uint32_t c = cnt > 0 ? (uint32_t)cnt : 0u;
+    const uint32_t incl = wave_incl_scan_u32(c, lane);
+    if ((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) != (uint32_t)size) bad = 1;  // (the serial walk would not end on cell 0)
+    if (!bad)
+      for (uint32_t k = incl - c; k < incl; k++) symtab[(k * (uint32_t)step) & (uint32_t)mask] = (uint8_t)lane;
+  } else {
+    if (lane == 0) {
+      int high = size - 1;
+      for (int s = 0; s < nsym; s++)
+        if (norm[s] == -1) symtab[high--] = (uint8_t)s;
+      int pos = 0;
+      for (int s = 0; s < nsym; s++) {
+        for (int i = 0; i < norm[s]; i++) {
+          symtab[pos] = (uint8_t)s;
+          do {
+            pos = (pos + step) & mask;
+          } while (pos > high);
+        }
       }
+      if (pos != 0) bad = 1;
     }
-    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
-    int pos = 0;
-    for (int s = 0; s < nsym; s++) {
-      for (int i = 0; i < norm[s]; i++) {
-        symtab[pos] = (uint8_t)s;
-        do {
-          pos = (pos + step) & mask;
-        } while (pos > high);
-      }
-    }
-    if (pos != 0) bad = 1;
-    for (int i = 0; i < size && !bad; i++) {
-      const int s = symtab[i];
-      const uint32_t ns = next[s]++;
+    bad = __shfl(bad, 0);
+  }
+  wave_sync();
+  if (bad) return 1;
+  (void)next;
+  if ((int)lane < nsym && cnt != 0) {
+    uint32_t ns = cnt == -1 ? 1u : (uint32_t)cnt;
+    const uint8_t add = which == 0 ? Z_LL_BITS[lane] : (which == 1 ? (uint8_t)lane : Z_ML_BITS[lane]);
+    const uint32_t base = which == 0 ? Z_LL_BASE[lane] : (which == 1 ? 1u << lane : Z_ML_BASE[lane]);
+    for (int i = 0; i < size; i++) {
+      if (symtab[i] != lane) continue;
       const int nb = log - z_hibit(ns);
       ZFse e;
-      e.next = (uint16_t)((ns << nb) - size);
+      e.next = (uint16_t)((ns << nb) - (uint32_t)size);
       e.nb = (uint8_t)nb;
-      if (which == 0) {
-        e.add = Z_LL_BITS[s];
-        e.base = Z_LL_BASE[s];
-      } else if (which == 1) {
-        e.add = (uint8_t)s;
-        e.base = 1u << s;
-      } else {
-        e.add = Z_ML_BITS[s];
-        e.base = Z_ML_BASE[s];
-      }
+      e.add = add;
+      e.base = base;
       t[i] = e;
+      ns++;
     }
   }
-  bad = __shfl(bad, 0);
   wave_sync();
-  return bad;
+  return 0;
 }
 
 // One table description (Predefined / RLE / FSE_Compressed) at p: builds it when `build`, returns the bytes it takes or -1.
@@ -446,11 +453,16 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------------
+// Two independent jobs per compressed block, each a workgroup of one wavefront: blockIdx.x < n_blocks decodes the
+// SEQUENCES of block blockIdx.x (the long serial chain: those workgroups come first), blockIdx.x >= n_blocks decodes the
+// LITERALS of block blockIdx.x - n_blocks.  status_out[job] = 0, or a diagnostic code (any nonzero value rejects the chunk).
 extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBlock* __restrict__ blocks, uint32_t n_blocks, uint32_t* dump_words,
                                                                      uint32_t* __restrict__ status_out) {
   __shared__ ZEntLds L;
-  const uint32_t b = blockIdx.x;
-  if (b >= n_blocks) return;
+  const uint32_t job = blockIdx.x;
+  if (job >= 2 * n_blocks) return;
+  const bool lit_job = job >= n_blocks;
+  const uint32_t b = lit_job ? job - n_blocks : job;
   const uint32_t lane = threadIdx.x;
   PROF_BEGIN();
   ZBlock B = blocks[b];
@@ -460,7 +472,7 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
   uint32_t* dump = (uint32_t*)as_global((void*)dump_words) + (size_t)(b & 1023u) * 64;
   int st = 0;
   // ---- literals ----
-  if (B.lit_type >= 2) {
+  if (lit_job && B.lit_type >= 2) {
     int mb = 0;
     PROF_MARK(0);
     const uint8_t* q = src + B.content_off + B.lit_hdr;
@@ -508,7 +520,7 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
     PROF_MARK(2);
   }
   // ---- sequences ----
-  if (!st && B.nseq) {
+  if (!lit_job && B.nseq) {
     int ll_log = 0, of_log = 0, ml_log = 0;
     uint32_t p = B.seq_off + 1;  // own descriptions follow the modes byte
     const uint32_t end = B.content_end;
@@ -531,9 +543,9 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
       if (p > end) st = 20;
       else st = zfse_sequences(L, src + p, end - p, B.nseq, ll_log, of_log, ml_log, seq_out, dump, lane);
     }
+    PROF_MARK(4);
+    PROF_COUNT(4, B.nseq);
   }
-  PROF_MARK(4);
-  PROF_COUNT(4, B.nseq);
   PROF_END_AT(112);
-  if (lane == 0) status_out[b] = (uint32_t)st;
+  if (lane == 0) status_out[job] = (uint32_t)st;
 }

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -126,8 +127,16 @@ struct StagedStream {
 };
 }  // namespace
 
+constexpr int kMaxLanes = 4;
+
+// A context decodes the columns of a call on up to kMaxLanes LANES at once: a lane is a HIP stream with its own workspace,
+// pinned summary buffer and events (lane 0 = the context itself, the others are child contexts driven by their own host
+// thread for the duration of a call).  Columns are independent (stripe.rs:154-165), so lanes share nothing but the
+// staged stripes (read only) and write disjoint columns of the results.
 struct orcgpu_ctx {
   int device = 0;
+  int lane_id = 0;
+  orcgpu_ctx* lanes[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};  // [0] = this
   hipStream_t stream = nullptr;
   std::string err;
   DevBuf scratch;
@@ -176,6 +185,7 @@ struct ColumnOut {
   uint32_t precision = 0, scale = 0;
   bool has_present = false;
   uint64_t values_off = 0, values_bytes = 0;      // in the result arena (or the chars arena)
+  int lane = 0;                                   // which lane's arenas hold the column
   bool values_in_chars = false;                   // dictionary strings: values live in orcgpu_result::chars
   uint64_t offsets_off = 0;                       // strings: n_batches * (B+1) int32
   uint64_t validity_off = 0;                      // n_batches * words_per_batch u64
@@ -192,8 +202,8 @@ struct orcgpu_result {
   orcgpu_ctx* ctx = nullptr;
   uint64_t n_rows = 0;
   uint32_t batch = 8192, n_batches = 0, words_per_batch = 0;
-  DevBuf arena;
-  DevBuf chars;  // dictionary -> Utf8 materialised value bytes (sized after the lengths are known)
+  DevBuf arena[kMaxLanes];  // per lane: the Arrow buffers of the columns that lane decoded
+  DevBuf chars[kMaxLanes];  // dictionary -> Utf8 materialised value bytes (sized after the lengths are known)
   std::vector<ColumnOut> cols;
   int status = 0;
   uint32_t err_batch = 0, err_col = 0;
@@ -358,6 +368,7 @@ struct ColPlan {
 };
 
 struct Plan {
+  int lane_id = 0;
   std::vector<orcgpu_staged*> stripes;
   std::vector<orcgpu_result*> results;
   std::vector<ColPlan> cols;
@@ -403,11 +414,17 @@ orcgpu_ctx* orcgpu_open(int device, const orcgpu_opts* opts) {
       return nullptr;
     }
   if (opts && opts->workspace_bytes) c->scratch.ensure(opts->workspace_bytes);
+  c->lanes[0] = c;
   return c;
 }
 
 void orcgpu_close(orcgpu_ctx* c) {
   if (!c) return;
+  for (int k = 1; k < kMaxLanes; k++)
+    if (c->lanes[k]) {
+      orcgpu_close(c->lanes[k]);
+      c->lanes[k] = nullptr;
+    }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->scratch.release();
