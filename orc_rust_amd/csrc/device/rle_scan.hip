@@ -570,88 +570,143 @@ __device__ __forceinline__ uint32_t count_lds(const uint8_t* buf, const uint8_t*
   return nv;
 }
 
+// Exit and value count of one block for EVERY entry at once: every byte position of the block is parsed as if a run started
+// there (next[p] = where that run ends, cnt[p] = its values; an unparsable position hops one byte like the walks do), then
+// pointer doubling inside the block makes next[p] the first position at or behind the block's end that the chain from p
+// reaches, and cnt[p] the values of the runs on the way.  Cost: 8 parses + at most 9 x 8 table updates per lane, whatever
+// the data -- no serial chain through the block, and no dependence on how quickly wrong chains merge with the true one.
 template <int CODEC>
-__device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t lb0, uint32_t b0g, uint8_t* buf, uint32_t lane,
-                                           bool live, bool weak PROF_PARM) {
-  const uint8_t* data = as_global(j->data);
-  const bool is_signed = j->is_signed;
-  const int nbits = j->nbits;
-  const uint32_t wstart = lb0 >= RLE_WARM ? lb0 - RLE_WARM : 0u;
-  const uint32_t nwarm = lb0 - wstart;
-  const uint64_t gstart = (uint64_t)wstart * RLE_BLK;
-  uint64_t gend = (uint64_t)(lb0 + 64) * RLE_BLK + ORC_PAD;
-  if (gend > len + ORC_PAD) gend = len + ORC_PAD;
-  // stage the bytes (coalesced 16-byte pieces)
-  for (uint64_t o0 = (uint64_t)lane * 16; gstart + o0 < gend; o0 += 8 * 64 * 16) {
-    uint4 v[8];
+__device__ __forceinline__ void block_exit_table(const uint8_t* data, uint64_t len, uint32_t lbv, bool is_signed, int nbits, uint16_t (*tab)[RLE_BLK],
+                                                 uint32_t lane, int& cur) {
+  const uint64_t bstart = (uint64_t)lbv * RLE_BLK;
+  const uint32_t limit = len - bstart < RLE_BLK ? (uint32_t)(len - bstart) : RLE_BLK;  // positions below it lie inside the stream
+  cur = 0;
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      uint64_t o = o0 + (uint64_t)u * 64 * 16;
-      if (gstart + o < gend) __builtin_memcpy(&v[u], data + gstart + o, 16);
+  for (int i = 0; i < 8; i++) {
+    const uint32_t p = lane + 64u * i;
+    uint32_t nx = 0xffffu, c = 0;
+    if (p < limit) {
+      uint32_t sz, n, err;
+      const uint64_t pos = bstart + p;
+      if (CODEC == CODEC_RLE2 && len - pos >= 32) {
+        // 32 or more bytes left: whatever the lean parse rejects is an error for the full parse too (the walks hop one
+        // byte then), so the table needs nothing else -- and most byte positions of a block are no run header at all.
+        // (Windows come straight from memory: neighbouring lanes read neighbouring bytes, the block sits in L2.)
+        const Win24 win = ld_win24(data + pos);
+        err = !(rle2_lean(win, nbits, sz, n) && sz <= len - pos);
+      } else {
+        hop_parse<CODEC>(data + pos, len - pos, is_signed, nbits, sz, n, err);
+      }
+      const uint32_t to = p + (err ? 1u : sz);
+      nx = to < 0xffffu ? to : 0xfffeu;
+      c = err ? 0u : n;
     }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      uint64_t o = o0 + (uint64_t)u * 64 * 16;
-      if (gstart + o < gend) __builtin_memcpy(buf + o, &v[u], 16);
-    }
+    tab[0][p] = (uint16_t)nx;
+    tab[1][p] = (uint16_t)c;
   }
   wave_sync_scan();
-  PROF_MARK(5);
-  uint32_t E = 0;
-  const bool first_weak = __shfl((int)weak, 0);
-  if (nwarm > 0 && first_weak) {
-    // warm-up phase: lanes 0..nwarm-1 own the blocks in front of the span
-    uint32_t e = 0, ex = 0;
-    bool dirty = lane < nwarm;
-    for (int it = 0; it < 64; it++) {
-#ifdef ORC_PROF
-      if (lane == 0) atomicAdd(&g_prof[40], 1ull);
-#endif
-      if (dirty) walk_lds<CODEC>(buf, data, gstart, gend, len, wstart + lane, e, is_signed, nbits, &ex);
-      uint32_t prev = __shfl_up(ex, 1);
-      uint32_t ne = (lane == 0 || lane >= nwarm) ? e : prev;
-      dirty = ne != e;
-      e = ne;
-      if (!__ballot(dirty)) break;
-    }
-    E = __shfl(ex, nwarm - 1);
-  }
-  PROF_MARK(6);
-  // span phase
-  uint32_t b = b0g + lane;
-  uint32_t e = 0, ex = 0;
-  if (live) e = weak ? (lane == 0 ? (lb0 == 0 ? 0u : E) : 0u) : blk.entry[b];
-  bool dirty = live;
-  for (int it = 0; it < 96; it++) {
-#ifdef ORC_PROF
-    if (lane == 0) atomicAdd(&g_prof[41], 1ull);
-#endif
-    if (dirty) {
-      if (e >= RLE_BLK) {
-        ex = e - RLE_BLK;
-      } else {
-        walk_lds<CODEC>(buf, data, gstart, gend, len, lb0 + lane, e, is_signed, nbits, &ex);
+  for (int round = 0; round < 10; round++) {
+    uint16_t* nx0 = tab[2 * cur];
+    uint16_t* cn0 = tab[2 * cur + 1];
+    uint16_t* nx1 = tab[2 * (cur ^ 1)];
+    uint16_t* cn1 = tab[2 * (cur ^ 1) + 1];
+    bool changed = false;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint32_t p = lane + 64u * i;
+      uint32_t q = nx0[p], c = cn0[p];
+      if (q < limit) {
+        c += cn0[q];
+        q = nx0[q];
+        changed = true;
       }
+      nx1[p] = (uint16_t)q;
+      cn1[p] = (uint16_t)c;
     }
-    uint32_t prev = __shfl_up(ex, 1);
-    uint32_t ne = (weak && lane > 0) ? prev : e;
-    dirty = live && ne != e;
-    e = ne;
-    if (!__ballot(dirty)) break;
-  }
-  PROF_MARK(7);
-  if (live && weak) {
-    uint32_t nv = e >= RLE_BLK ? 0u : count_lds<CODEC>(buf, data, gstart, gend, len, lb0 + lane, e, is_signed, nbits);
-    blk.entry[b] = e;
-    blk.exit_[b] = ex;
-    blk.nvals[b] = nv;
+    wave_sync_scan();
+    cur ^= 1;
+    if (!__ballot(changed)) break;
   }
 }
 
-extern "C" __global__ void __launch_bounds__(64) rle_walk_short_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
-                                                                        uint32_t total_blocks, uint32_t spans_per_wg) {
-  __shared__ __attribute__((aligned(16))) uint8_t buf[(64 + RLE_WARM) * RLE_BLK + 2 * ORC_PAD];
-  uint32_t lane = threadIdx.x;
+#define RLE_SHORT_WAVES 8
+// One span by a workgroup of RLE_SHORT_WAVES wavefronts: per round every wave builds the all-entries table of one block
+// (block_exit_table: the expensive, entry-independent part), then the chain takes one table lookup per block.
+template <int CODEC>
+__device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t lb0, uint32_t b0g, uint16_t (*tabs)[4][RLE_BLK],
+                                           int* curs, uint32_t tid, unsigned long long live_m, unsigned long long weak_m PROF_PARM) {
+  const uint8_t* data = as_global(j->data);
+  const bool is_signed = j->is_signed;
+  const int nbits = j->nbits;
+  const uint32_t lane = tid & 63, wv = tid >> 6;
+  const uint32_t wstart = lb0 >= RLE_WARM ? lb0 - RLE_WARM : 0u;
+  const uint32_t nwarm = lb0 - wstart;
+  // The warm-up blocks in front of the span come first (entry 0 at the first one: a chain started at a wrong byte merges
+  // with the true chain after a few run lengths), then the span's own.  A weak block enters where its predecessor's last
+  // run ended, a strong one at its verified header.
+  const bool first_weak = weak_m & 1;
+  uint32_t run_exit = 0;  // where the previous block's last run ended (relative to this block's start)
+  const uint32_t k0 = (nwarm > 0 && first_weak) ? 0u : nwarm;
+  for (uint32_t kr = k0; kr < nwarm + 64; kr += RLE_SHORT_WAVES) {
+    {
+      const uint32_t k = kr + wv;
+      const bool in_span = k >= nwarm;
+      const bool there = k < nwarm + 64 && (!in_span || ((live_m >> (k - nwarm)) & 1)) && (uint64_t)(wstart + k) * RLE_BLK < len;
+      int cur = 0;
+      if (there) block_exit_table<CODEC>(data, len, wstart + k, is_signed, nbits, tabs[wv], lane, cur);
+      if (lane == 0) curs[wv] = cur;
+    }
+    __syncthreads();
+    bool done = false;
+    for (uint32_t w = 0; w < RLE_SHORT_WAVES; w++) {
+      const uint32_t k = kr + w;
+      if (k >= nwarm + 64) break;
+      const bool in_span = k >= nwarm;
+      const uint32_t sl = k - nwarm;
+      if (in_span && !((live_m >> sl) & 1)) {
+        done = true;
+        break;
+      }
+      const bool bweak = !in_span || ((weak_m >> sl) & 1);
+      const uint32_t lbv = wstart + k;
+      uint32_t e;
+      if (!bweak) e = blk.entry[b0g + sl];
+      else if (k == k0) e = 0;  // (first warm-up block, or the stream's first block)
+      else e = run_exit;
+      uint32_t ex, nv = 0;
+      if (e >= RLE_BLK) {
+        ex = e - RLE_BLK;
+      } else {
+        const uint64_t bstart = (uint64_t)lbv * RLE_BLK;
+        const uint32_t limit = bstart >= len ? 0u : (len - bstart < RLE_BLK ? (uint32_t)(len - bstart) : RLE_BLK);
+        if (e >= limit) {
+          ex = 0;
+        } else {
+          const int cur = curs[w];
+          const uint32_t to = tabs[w][2 * cur][e];
+          nv = tabs[w][2 * cur + 1][e];
+          ex = to > RLE_BLK ? to - RLE_BLK : 0u;
+        }
+      }
+      run_exit = ex;
+      if (in_span && bweak && tid == 0) {
+        blk.entry[b0g + sl] = e;
+        blk.exit_[b0g + sl] = ex;
+        blk.nvals[b0g + sl] = nv;
+      }
+    }
+    __syncthreads();
+    if (done) break;
+  }
+  PROF_MARK(7);
+}
+
+extern "C" __global__ void __launch_bounds__(64 * RLE_SHORT_WAVES) rle_walk_short_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
+                                                                                          uint32_t total_blocks, uint32_t spans_per_wg) {
+  __shared__ uint16_t tabs[RLE_SHORT_WAVES][4][RLE_BLK];
+  __shared__ int curs[RLE_SHORT_WAVES];
+  __shared__ unsigned long long masks[8][2];
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
   // up to eight spans per workgroup (the host picks a power of two; block ranges of a job are
   // RLE_TILE aligned, so they belong to one stream): their flags are fetched together, spans with
   // few weak blocks cost nothing more.  Big batches of long-run streams have thousands of spans
@@ -662,24 +717,30 @@ extern "C" __global__ void __launch_bounds__(64) rle_walk_short_kernel(RleJob* j
   PROF_BEGIN();
   RleJob* j = const_cast<RleJob*>(find_job_by_block(jobs, njobs, bw8));
   uint64_t len = scalars[j->len_idx];
-  bool live8[8], weak8[8];
+  if (tid < 64) {
 #pragma unroll
-  for (int s = 0; s < 8; s++) {
-    uint32_t lb = bw8 - j->block0 + s * 64 + lane;
-    live8[s] = (uint32_t)s < spans_per_wg && lb < j->nblocks && ((uint64_t)lb * RLE_BLK < len || lb == 0);
-    weak8[s] = live8[s] && !blk.flags[bw8 + s * 64 + lane];
+    for (int s = 0; s < 8; s++) {
+      uint32_t lb = bw8 - j->block0 + s * 64 + lane;
+      const bool live = (uint32_t)s < spans_per_wg && lb < j->nblocks && ((uint64_t)lb * RLE_BLK < len || lb == 0);
+      const bool weak = live && !blk.flags[bw8 + s * 64 + lane];
+      const unsigned long long lm = __ballot(live), wm = __ballot(weak);
+      if (lane == 0) {
+        masks[s][0] = lm;
+        masks[s][1] = wm;
+      }
+    }
   }
-#pragma unroll
+  __syncthreads();
   for (int s = 0; s < 8; s++) {
+    const unsigned long long live_m = masks[s][0], weak_m = masks[s][1];
     // isolated weak blocks inside long-run streams are left to the relaxation rounds
-    if (__builtin_popcountll(__ballot(weak8[s])) < 16) continue;
+    if (__builtin_popcountll(weak_m) < 16) continue;
     uint32_t bw = bw8 + s * 64, lb0 = bw - j->block0;
-    if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, buf, lane, live8[s], weak8[s] PROF_ARG);
-    else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, buf, lane, live8[s], weak8[s] PROF_ARG);
-    else short_span<CODEC_BYTE>(j, blk, len, lb0, bw, buf, lane, live8[s], weak8[s] PROF_ARG);
-    wave_sync_scan();
+    if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, tabs, curs, tid, live_m, weak_m PROF_ARG);
+    else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, tabs, curs, tid, live_m, weak_m PROF_ARG);
+    else short_span<CODEC_BYTE>(j, blk, len, lb0, bw, tabs, curs, tid, live_m, weak_m PROF_ARG);
 #ifdef ORC_PROF
-    if (lane == 0) atomicAdd(&g_prof[42], 1ull);
+    if (tid == 0) atomicAdd(&g_prof[42], 1ull);
 #endif
     PROF_MARK(8);
   }
