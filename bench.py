@@ -18,11 +18,14 @@ orcgpu_last_phase_ms) against the HBM peak with the ALGORITHMIC bytes of SURVEY 
 bytes out.  `cpu_baseline` = the CPU oracle (a C port of the reference's algorithm; the Rust reference cannot be
 built here) on a bounded sample of the same stripes on this box's host cores, 1 thread and all cores.
 
-Multi-GPU (`--gpus N`): the path shards with no data-path collective.  lineitem: COLUMN shard -- the 16 columns are
-spread over the ranks balanced by their Arrow bytes (orc_rust_amd.shard.column_shard), every rank stages and decodes
-only its own columns of every stripe; c2 / c5: STRIPE shard (round robin).  The total work is fixed ("strong"
-scaling).  The only exchange is one all-gather (RCCL) of {rows, value bytes of the rank's string columns, Arrow
-bytes, error word}; rank 0 checks that every column was decoded exactly once and that the row counts agree.
+Multi-GPU (`--gpus N`): the path shards with no data-path collective, one process per GPU.  lineitem: the table grows
+with the job (scale factor N: N x 6 001 215 rows, "weak" scaling -- BASELINE's C4 is SF100 over 8 GPUs, and a
+Zstandard stripe decodes no faster when fewer of them share a GPU: its entropy stage is a serial chain per block) and
+is cut into (stripe, column) UNITS spread over the ranks by their Arrow bytes, longest first
+(orc_rust_amd.shard.unit_shard): every rank generates, stages and decodes only its own columns of its own stripes.
+c2 / c3 / c5: STRIPE shard (round robin) of N x the single-GPU row count.  The only exchange is one all-gather (RCCL)
+of {rows x columns decoded, value bytes of the rank's string columns, Arrow bytes, stream bytes, units, error word};
+rank 0 checks that every unit was decoded exactly once and that the row counts add up.
 """
 import argparse
 import json
@@ -52,19 +55,25 @@ def build_workload(args, rank, world):
     from orc_rust_amd.gen import workloads as W
     wl = args.workload
     if wl == "lineitem":
-        rows = args.rows or W.LINEITEM_SF1_ROWS
-        column_ids = None
-        desc = "all 16 columns"
-        if world > 1:
-            parts = shard.column_shard(W.LINEITEM_ARROW_BYTES_PER_ROW, world)
-            column_ids = [i + 1 for i in parts[rank]]
-            desc = "column shard x%d (LPT by Arrow bytes)" % world
-        stripes = W.lineitem_stripes(rows, W.LINEITEM_STRIPE_ROWS, args.compression or "zstd", column_ids=column_ids) if column_ids != [] else []
         comp = args.compression or "zstd"
-        label = ("C4: TPC-H-shaped lineitem stripes, SF1-sized (%d rows, 16 columns: 3 Int64, Int32, 4 Decimal128(15,2), 3 Date32, "
-                 "4 dictionary Utf8, 1 direct Utf8), %s, %d-row stripes" % (rows, comp, W.LINEITEM_STRIPE_ROWS))
-        return [s[:4] for s in stripes], comp, label, desc
-    rows = args.rows or C2_ROWS
+        rows = (args.rows or W.LINEITEM_SF1_ROWS) * world
+        stripe_rows = [min(W.LINEITEM_STRIPE_ROWS, rows - lo) for lo in range(0, rows, W.LINEITEM_STRIPE_ROWS)]
+        units, loads = shard.unit_shard(stripe_rows, W.LINEITEM_ARROW_BYTES_PER_ROW, world)
+        mine = units[rank]
+        desc = "all 16 columns of every stripe" if world == 1 else "(stripe, column) units x%d, LPT by Arrow bytes" % world
+        by_stripe = {}
+        for s_, c_ in mine:
+            by_stripe.setdefault(s_, []).append(c_ + 1)
+        names = sorted({W.LINEITEM[c - 1][0] for cs in by_stripe.values() for c in cs})
+        table = W.lineitem_table(rows, 7, names=names) if mine else {}
+        stripes = []
+        for s_ in sorted(by_stripe):
+            lo = s_ * W.LINEITEM_STRIPE_ROWS
+            stripes.append(W.lineitem_stripe(table, lo, lo + stripe_rows[s_], comp, column_ids=by_stripe[s_]))
+        label = ("C4: TPC-H-shaped lineitem stripes, scale factor %d (%d rows, 16 columns: 3 Int64, Int32, 4 Decimal128(15,2), 3 Date32, "
+                 "4 dictionary Utf8, 1 direct Utf8), %s, %d-row stripes" % (world, rows, comp, W.LINEITEM_STRIPE_ROWS))
+        return stripes, comp, label, desc, {"units": mine, "n_stripes": len(stripe_rows), "n_columns": 16, "rows": rows}
+    rows = (args.rows or C2_ROWS) * world
     n_stripes = (rows + C2_STRIPE_ROWS - 1) // C2_STRIPE_ROWS
     mine = shard.stripe_shard(n_stripes, rank, world)
     desc = "all stripes" if world == 1 else "stripe shard x%d (round robin)" % world
@@ -91,7 +100,7 @@ def build_workload(args, rank, world):
         label = "C5: Timestamp(ns), PATCHED_BASE seconds + DIRECT nanoseconds, %d rows, %s, %d stripes" % (rows, comp, n_stripes)
     else:
         raise SystemExit("unknown workload " + wl)
-    return stripes, comp, label, desc
+    return stripes, comp, label, desc, {"units": [(s_, 0) for s_ in mine], "n_stripes": n_stripes, "n_columns": 1, "rows": rows}
 
 
 _TASKS = []  # (n_rows, column, {kind: bytes}, compression): filled before the worker processes are forked
@@ -193,7 +202,7 @@ def main():
                          "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ...`" % (args.gpus, args.gpus, world, args.gpus, args.gpus))
     # The workload and the CPU baseline come first: the baseline forks worker processes, which must happen before
     # this process initialises the GPU.
-    stripes, comp, label, shard_desc = build_workload(args, rank, world)
+    stripes, comp, label, shard_desc, plan = build_workload(args, rank, world)
     cpu = None
     if rank == 0 and not args.no_cpu and world == 1 and stripes:  # timed on rank 0 at N=1 only
         cpu = cpu_baseline(stripes, comp)
@@ -259,24 +268,20 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     string_bytes = sum(sum(len(e["values"]) for cid, e in expect.items() if "lengths" in e) for _, _, _, expect in stripes)
+    unit_rows = sum(n * len(cols) for n, cols, _, _ in stripes)  # rows x columns this rank decoded
     if dist is not None:
         tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        # the path's only exchange: {rows, value bytes of this rank's string columns, Arrow bytes, stream bytes, columns, error word}
-        ncols = len(stripes[0][1]) if stripes else 0
-        allc = shard.gather_counts([rows, string_bytes, arrow_bytes, stream_bytes, ncols, err_word], dist, coll_dev)
+        # the path's only exchange: {rows x columns, value bytes of this rank's string columns, Arrow bytes, stream bytes, units, error word}
+        allc = shard.gather_counts([unit_rows, string_bytes, arrow_bytes, stream_bytes, len(plan["units"]), err_word], dist, coll_dev)
         total_arrow = sum(c[2] for c in allc)
         total_stream = sum(c[3] for c in allc)
         assert all(c[5] == 0 for c in allc), "a rank reported a decode error"
-        if args.workload == "lineitem":
-            per_rank_rows = {c[0] for c in allc if c[4]}
-            assert len(per_rank_rows) == 1, "column shards disagree on the row count: %s" % allc
-            assert sum(c[4] for c in allc) == 16, "every column must be decoded exactly once"
-            total_rows = per_rank_rows.pop()
-        else:
-            total_rows = sum(c[0] for c in allc)
-        per_rank = [{"rows": c[0], "string_bytes": c[1], "arrow_bytes": c[2], "stream_bytes": c[3], "columns": c[4]} for c in allc]
+        assert sum(c[4] for c in allc) == plan["n_stripes"] * plan["n_columns"], "every (stripe, column) unit must be decoded exactly once"
+        assert sum(c[0] for c in allc) == plan["rows"] * plan["n_columns"], "decoded rows do not add up: %s" % allc
+        total_rows = plan["rows"]
+        per_rank = [{"rows_x_columns": c[0], "string_bytes": c[1], "arrow_bytes": c[2], "stream_bytes": c[3], "units": c[4]} for c in allc]
     else:
         total_rows, total_arrow, total_stream = rows, arrow_bytes, stream_bytes
         per_rank = None
@@ -290,7 +295,7 @@ def main():
     out = {
         "metric": "decoded GB/s + Mrows/s into Arrow, TPC-H lineitem stripe" if args.workload == "lineitem" else "decoded GB/s + Mrows/s into Arrow",
         "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int64" if args.workload.startswith(("c2", "c5")) else ("u8" if args.workload == "c3" else "int64/i128/u8"),
         "data": "synthetic",
         "config": {"workload": label, "rows": total_rows, "stripes": len(stripes), "batch_size": 8192, "compression": comp,

@@ -258,7 +258,9 @@ void scan_chunks(const uint8_t* ptr, uint64_t len_total, int compression, uint64
         shift += 7;
         if (!(c & 0x80)) break;
       }
-      if (u <= (1ull << 31)) cap = (uint32_t)u;
+      // (a block that claims more than the compression block size -- no writer emits one -- gets the block size: the
+      // decoder then rejects it as it would a block whose output overruns its slot)
+      cap = (uint32_t)std::min<uint64_t>(u, std::max<uint64_t>(block_size, 1u << 22));
     }
     ChunkInfo ci{p + 3, len, h & 1, cap, -1};
     if (!(h & 1) && compression == ORCGPU_COMP_ZSTD) {
@@ -440,6 +442,16 @@ const char* orcgpu_last_error(const orcgpu_ctx* c) { return c ? c->err.c_str() :
 // ---- staging --------------------------------------------------------------------------------------
 int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_staged** out) {
   if (!ctx || !d || !out) return ORCGPU_INVALID_ARGUMENT;
+  // Row counts and block sizes come from file footers: every buffer of a decode is sized from them (and ranks / value
+  // offsets are 32-bit), so absurd values are refused here instead of wrapping a size computation later.
+  if (d->n_rows >= (1ull << 31)) {
+    set_err(ctx, "stripe with %llu rows: more than 2^31 - 1 rows per stripe are not supported", (unsigned long long)d->n_rows);
+    return ORCGPU_INVALID_ARGUMENT;
+  }
+  if (d->block_size > (1ull << 30)) {
+    set_err(ctx, "compression block size %llu is larger than 1 GiB", (unsigned long long)d->block_size);
+    return ORCGPU_INVALID_ARGUMENT;
+  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   orcgpu_staged* s = new orcgpu_staged();
   s->ctx = ctx;

@@ -62,6 +62,55 @@ def test_sharding_helpers():
     assert max(loads) == 44 and min(loads) >= 16
 
 
+def test_unit_shard_balances_and_covers():
+    from orc_rust_amd import shard
+    costs = [8, 8, 8, 4, 16, 16, 16, 16, 5, 5, 4, 4, 4, 16, 8.3, 30.5]
+    stripe_rows = [2_189_312] * 21 + [2_034_168]
+    for world in (1, 2, 4, 8):
+        units, loads = shard.unit_shard(stripe_rows, costs, world)
+        shard.check_unit_coverage(units, len(stripe_rows), len(costs))
+        assert max(loads) <= 1.02 * (sum(loads) / world)
+    offs, total = shard.stripe_row_offsets(stripe_rows)
+    assert offs[1] == 2_189_312 and total == sum(stripe_rows)
+
+
+_BENCH_WORKER = r"""
+import os, sys, types
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import bench
+from orc_rust_amd import shard
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+# the multi-rank path of bench.py up to the point where a GPU is needed: this rank's units, their stripes, the all-gather
+args = types.SimpleNamespace(workload="lineitem", rows=30000, compression="none")
+stripes, comp, label, desc, plan = bench.build_workload(args, rank, world)
+assert plan["rows"] == 30000 * world and plan["n_columns"] == 16
+unit_rows = sum(n * len(cols) for n, cols, _, _ in stripes)
+allc = shard.gather_counts([unit_rows, 0, 0, sum(len(b) for _, _, st, _ in stripes for _, _, b in st), len(plan["units"]), 0], dist)
+assert sum(c[4] for c in allc) == plan["n_stripes"] * 16
+assert sum(c[0] for c in allc) == plan["rows"] * 16
+allu = [None] * world
+dist.all_gather_object(allu, plan["units"])
+shard.check_unit_coverage(allu, plan["n_stripes"], 16)
+# every rank holds only the columns of its units
+for (n, cols, streams, expect), s_ in zip(stripes, sorted({u[0] for u in plan["units"]})):
+    assert sorted(c["column_id"] - 1 for c in cols) == sorted(c for s2, c in plan["units"] if s2 == s_)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_rank_gloo_bench_sharding(tmp_path):
+    script = tmp_path / "bench_worker.py"
+    script.write_text(_BENCH_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+
+
 _WORKER = r"""
 import os, sys
 sys.path.insert(0, %r)
