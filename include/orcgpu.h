@@ -117,9 +117,13 @@ const char* orcgpu_last_error(const orcgpu_ctx* ctx);
 const char* orcgpu_version(void);
 
 /* ---- staging: host stream bytes -> HBM --------------------------------------------------------- */
-/* Copies every stream of the stripe into one HBM arena through a pinned bounce buffer
- * (hipMemcpyAsync) and scans the 3-byte chunk headers (compression.rs:113-123, :244-267) on the
- * host while the bytes are at hand.  The returned handle keeps its own copy of the descriptor. */
+/* Copies every stream of the stripe into one HBM arena (taken from a pool) and scans the 3-byte chunk headers
+ * (compression.rs:113-123, :244-267; Zstandard: also the frame / block headers) on the host while the bytes are at hand.
+ * The copy is a pipeline: 16 MiB pieces go through two pinned buffers, filled by a few host threads while the previous
+ * piece is on its way (hipMemcpyAsync on a copy stream).  The call does NOT wait for the last piece: decodes wait for
+ * it on the device, so staging stripe k + 1 overlaps decoding stripe k (the analogue of the reference's
+ * Stripe::new reading ahead, stripe.rs:127-182 / async_arrow_reader.rs:165-280).  The caller's buffers may be
+ * reused as soon as the call returns.  The returned handle keeps its own copy of the descriptor. */
 int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* desc, orcgpu_staged** out);
 void orcgpu_staged_free(orcgpu_staged* s);
 uint64_t orcgpu_staged_bytes(const orcgpu_staged* s); /* sum of Stream.length staged in HBM */
@@ -159,6 +163,12 @@ int orcgpu_result_batch_view(const orcgpu_result* r, uint32_t batch, uint32_t co
 /* Copies one column-batch to host memory supplied by the caller (sizes from the view). */
 int orcgpu_result_copy_batch(orcgpu_ctx* ctx, const orcgpu_result* r, uint32_t batch, uint32_t column, void* values,
                              int32_t* offsets, void* validity);
+
+/* Brings every Arrow buffer of the result to the host at once: one hipMemcpyAsync per result arena into pinned memory
+ * (the counterpart of the reference handing out freshly allocated host buffers, array_decoder/mod.rs:100-120), one
+ * synchronisation.  orcgpu_result_export_batch calls it on demand; the exported batches are views into that copy and
+ * keep it alive after orcgpu_result_free. */
+int orcgpu_result_fetch(orcgpu_ctx* ctx, orcgpu_result* r);
 
 /* ---- Arrow C Data Interface export (https://arrow.apache.org/docs/format/CDataInterface.html) ---- */
 struct ArrowSchema;

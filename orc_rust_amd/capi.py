@@ -20,7 +20,7 @@ EXPORTS = [
     "orcgpu_open", "orcgpu_close", "orcgpu_last_error", "orcgpu_version", "orcgpu_stage_stripe", "orcgpu_staged_free",
     "orcgpu_staged_bytes", "orcgpu_decode_staged", "orcgpu_stripe_decode", "orcgpu_result_free", "orcgpu_result_status",
     "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
-    "orcgpu_result_copy_batch", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
+    "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
     "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
     "orcgpu_reader_set_projection", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision",
     "orcgpu_reader_total_rows", "orcgpu_reader_stripe_count", "orcgpu_reader_column_count", "orcgpu_reader_column_name",
@@ -90,6 +90,7 @@ def load():
     L.orcgpu_result_arrow_bytes.argtypes = [C.c_void_p]
     L.orcgpu_result_batch_view.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(BatchView)]
     L.orcgpu_result_copy_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orcgpu_result_fetch.argtypes = [C.c_void_p, C.c_void_p]
     L.orcgpu_result_export_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.orcgpu_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.orcgpu_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
@@ -261,6 +262,10 @@ class Result:
             validity.ctypes.data if validity is not None else None))
         return {"status": 0, "length": n, "null_count": v.null_count, "validity": validity.tobytes() if validity is not None else None,
                 "values": values[:v.values_bytes].tobytes(), "offsets": offsets}
+
+    def fetch(self):
+        """One device-to-host copy of all the result's Arrow buffers (pinned memory); export_batch then makes views."""
+        self.ctx._check(self.ctx.L.orcgpu_result_fetch(self.ctx.h, self.h))
 
     def export_batch(self, batch):
         """Arrow C Data Interface export -> pyarrow.RecordBatch (zero-copy import of host buffers)."""

@@ -16,6 +16,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <cstdarg>
 #include <cstdio>
@@ -128,6 +131,91 @@ struct StagedStream {
 }  // namespace
 
 constexpr int kMaxLanes = 4;
+constexpr size_t kStagePiece = 16u << 20;  // bytes per pinned staging piece
+constexpr int kCopyThreads = 6;
+
+// A handful of host threads that copy slices of caller memory into the pinned staging piece (one thread's memcpy does
+// about 10 GB/s: less than the link takes).
+struct CopyPool {
+  struct Task {
+    uint8_t* dst;
+    const uint8_t* src;
+    size_t n;
+  };
+  std::vector<std::thread> threads;
+  std::mutex m;
+  std::condition_variable cv, done;
+  std::vector<Task> tasks;
+  size_t next = 0, pending = 0;
+  bool stop = false;
+  CopyPool() {
+    for (int i = 0; i < kCopyThreads; i++) threads.emplace_back([this] { run(); });
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> g(m);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : threads) t.join();
+  }
+  void run() {
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [this] { return stop || next < tasks.size(); });
+        if (stop) return;
+        t = tasks[next++];
+      }
+      if (t.src) memcpy(t.dst, t.src, t.n);
+      else memset(t.dst, 0, t.n);
+      {
+        std::lock_guard<std::mutex> g(m);
+        if (--pending == 0) done.notify_all();
+      }
+    }
+  }
+  // copies (src == nullptr: zero fill) the calling thread takes part in; returns when all are done
+  void copy_all(std::vector<Task>& ts) {
+    size_t total = 0;
+    for (auto& t : ts) total += t.n;
+    if (total < (1u << 20)) {  // not worth waking anybody
+      for (auto& t : ts) {
+        if (t.src) memcpy(t.dst, t.src, t.n);
+        else memset(t.dst, 0, t.n);
+      }
+      return;
+    }
+    // slices of at most 1 MiB so that the threads share large streams
+    std::vector<Task> sl;
+    for (auto& t : ts)
+      for (size_t o = 0; o < t.n; o += 1u << 20) sl.push_back(Task{t.dst + o, t.src ? t.src + o : nullptr, std::min<size_t>(1u << 20, t.n - o)});
+    {
+      std::lock_guard<std::mutex> g(m);
+      tasks.swap(sl);
+      next = 0;
+      pending = tasks.size();
+    }
+    cv.notify_all();
+    for (;;) {  // the caller works too
+      Task t;
+      {
+        std::lock_guard<std::mutex> g(m);
+        if (next >= tasks.size()) break;
+        t = tasks[next++];
+      }
+      if (t.src) memcpy(t.dst, t.src, t.n);
+      else memset(t.dst, 0, t.n);
+      std::lock_guard<std::mutex> g(m);
+      if (--pending == 0) done.notify_all();
+    }
+    std::unique_lock<std::mutex> g(m);
+    done.wait(g, [this] { return pending == 0; });
+    tasks.clear();
+    next = 0;
+  }
+};
 
 // A context decodes the columns of a call on up to kMaxLanes LANES at once: a lane is a HIP stream with its own workspace,
 // pinned summary buffer and events (lane 0 = the context itself, the others are child contexts driven by their own host
@@ -146,6 +234,15 @@ struct orcgpu_ctx {
   float last_total_ms = 0, last_expand_ms = 0;
   float last_phase_ms[ORCGPU_N_PHASES] = {0, 0, 0, 0, 0};
   uint32_t last_expand_launches = 0;
+  // ---- staging pipeline (lane 0 only): a copy stream, two pinned pieces filled by a few host threads while the other one
+  // is on its way to HBM, a pool of stripe arenas ----
+  hipStream_t copy_stream = nullptr;
+  uint8_t* piece[2] = {nullptr, nullptr};
+  hipEvent_t piece_ev[2] = {nullptr, nullptr};
+  bool piece_used[2] = {false, false};
+  int piece_next = 0;
+  std::vector<std::pair<uint8_t*, size_t>> arena_pool;  // freed staged arenas (device pointer, bytes)
+  struct CopyPool* copiers = nullptr;
   bool ensure_pinned(size_t n) {
     if (n <= pinned_cap) return true;
     if (pinned) (void)hipHostFree(pinned);
@@ -164,7 +261,9 @@ struct orcgpu_staged {
   std::vector<orcgpu_column> cols;
   std::vector<StagedStream> streams;
   uint8_t* dev = nullptr;
-  size_t dev_bytes = 0;
+  size_t dev_bytes = 0;     // bytes in use
+  size_t dev_cap = 0;       // bytes of the arena (it may come from the pool)
+  hipEvent_t ready = nullptr;  // recorded on the copy stream behind the stripe's last piece
   uint64_t stream_bytes = 0;
   const StagedStream* find(uint32_t col, int kind) const {
     for (auto& s : streams)
@@ -198,12 +297,33 @@ struct ColumnOut {
 
 }  // namespace
 
+// Host mirror of a result's arenas: ONE device-to-host copy per arena into pinned memory; exported batches are views into
+// it and keep it alive (reference count) after the result itself is gone.
+struct HostMirror {
+  std::atomic<int> refs{1};
+  uint8_t* arena[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  uint8_t* chars[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  size_t arena_cap[kMaxLanes] = {0, 0, 0, 0}, chars_cap[kMaxLanes] = {0, 0, 0, 0};
+  void unref() {
+    if (refs.fetch_sub(1) == 1) {
+      for (auto p : arena)
+        if (p) (void)hipHostFree(p);
+      for (auto p : chars)
+        if (p) (void)hipHostFree(p);
+      delete this;
+    }
+  }
+};
+
 struct orcgpu_result {
   orcgpu_ctx* ctx = nullptr;
   uint64_t n_rows = 0;
   uint32_t batch = 8192, n_batches = 0, words_per_batch = 0;
   DevBuf arena[kMaxLanes];  // per lane: the Arrow buffers of the columns that lane decoded
   DevBuf chars[kMaxLanes];  // dictionary -> Utf8 materialised value bytes (sized after the lengths are known)
+  size_t arena_used[kMaxLanes] = {0, 0, 0, 0}, chars_used[kMaxLanes] = {0, 0, 0, 0};  // bytes of the last decode
+  HostMirror* mirror = nullptr;  // filled by orcgpu_result_fetch
+  bool mirror_valid = false;
   std::vector<ColumnOut> cols;
   int status = 0;
   uint32_t err_batch = 0, err_col = 0;
@@ -430,6 +550,13 @@ void orcgpu_close(orcgpu_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->scratch.release();
+  delete c->copiers;
+  for (int k = 0; k < 2; k++) {
+    if (c->piece[k]) (void)hipHostFree(c->piece[k]);
+    if (c->piece_ev[k]) (void)hipEventDestroy(c->piece_ev[k]);
+  }
+  for (auto& a : c->arena_pool) (void)hipFree(a.first);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->pinned) (void)hipHostFree(c->pinned);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -475,38 +602,125 @@ int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_sta
     s->streams.push_back(std::move(st));
   }
   s->dev_bytes = align_up(b.off + ORC_PAD);
-  if (hipMalloc((void**)&s->dev, s->dev_bytes) != hipSuccess) {
-    set_err(ctx, "hipMalloc(%zu) for the staged stripe failed", s->dev_bytes);
-    delete s;
-    return ORCGPU_HIP_ERROR;
+  // ---- arena: from the pool (smallest that fits, at most twice the size) or a new allocation ----
+  {
+    int best = -1;
+    for (size_t k = 0; k < ctx->arena_pool.size(); k++)
+      if (ctx->arena_pool[k].second >= s->dev_bytes && ctx->arena_pool[k].second <= 2 * s->dev_bytes + (1u << 20) &&
+          (best < 0 || ctx->arena_pool[k].second < ctx->arena_pool[best].second))
+        best = (int)k;
+    if (best >= 0) {
+      s->dev = ctx->arena_pool[best].first;
+      s->dev_cap = ctx->arena_pool[best].second;
+      ctx->arena_pool.erase(ctx->arena_pool.begin() + best);
+    } else {
+      if (hipMalloc((void**)&s->dev, s->dev_bytes) != hipSuccess) {
+        // give the pool back to the device and try once more
+        for (auto& a : ctx->arena_pool) (void)hipFree(a.first);
+        ctx->arena_pool.clear();
+        if (hipMalloc((void**)&s->dev, s->dev_bytes) != hipSuccess) {
+          set_err(ctx, "hipMalloc(%zu) for the staged stripe failed", s->dev_bytes);
+          delete s;
+          return ORCGPU_HIP_ERROR;
+        }
+      }
+      s->dev_cap = s->dev_bytes;
+    }
   }
-  if (!ctx->ensure_pinned(s->dev_bytes)) {
-    set_err(ctx, "hipHostMalloc(%zu) failed", s->dev_bytes);
+  // ---- pipeline: pieces of the arena go through two pinned buffers; while one is on its way to HBM (copy stream) the
+  // host threads fill the other.  Nothing waits for the last piece: `ready` is recorded behind it and the decode
+  // streams wait for that event, so staging stripe k + 1 overlaps decoding stripe k. ----
+  auto fail = [&](const char* what, hipError_t e) {
+    set_err(ctx, "%s failed: %s", what, hipGetErrorString(e));
+    (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipFree(s->dev);
+    if (s->ready) (void)hipEventDestroy(s->ready);
     delete s;
     return ORCGPU_HIP_ERROR;
+  };
+  hipError_t e = hipSuccess;
+  if (!ctx->copy_stream) {
+    e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; k++) {
+      e = hipHostMalloc((void**)&ctx->piece[k], kStagePiece + 4096, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->piece_ev[k], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) ctx->copiers = new CopyPool();
+    if (e != hipSuccess) {
+      ctx->copy_stream = nullptr;
+      return fail("setting up the staging pipeline", e);
+    }
   }
-  // pinned bounce buffer -> one hipMemcpyAsync for the whole stripe
-  (void)hipStreamSynchronize(ctx->stream);  // the bounce buffer may still feed an earlier copy
-  for (uint32_t i = 0; i < d->n_streams; i++) {
-    if (d->streams[i].len) memcpy(ctx->pinned + s->streams[i].off, d->streams[i].ptr, d->streams[i].len);
-    memset(ctx->pinned + s->streams[i].off + d->streams[i].len, 0, ORC_PAD);
+  e = hipEventCreateWithFlags(&s->ready, hipEventDisableTiming);
+  if (e != hipSuccess) return fail("hipEventCreate", e);
+  {
+    // the arena as a list of segments: stream bytes, then ORC_PAD zero bytes behind each
+    struct Seg {
+      uint64_t off;
+      const uint8_t* src;
+      uint64_t n;
+    };
+    std::vector<Seg> segs;
+    for (uint32_t i = 0; i < d->n_streams; i++) {
+      if (d->streams[i].len) segs.push_back(Seg{s->streams[i].off, d->streams[i].ptr, d->streams[i].len});
+      segs.push_back(Seg{s->streams[i].off + d->streams[i].len, nullptr, ORC_PAD});
+    }
+    size_t si = 0;
+    uint64_t within = 0;  // bytes of segs[si] already sent
+    uint64_t pos = 0;     // arena offset where the next piece starts
+    std::vector<CopyPool::Task> tasks;
+    while (si < segs.size()) {
+      pos = segs[si].off + within;
+      const int k = ctx->piece_next;
+      ctx->piece_next ^= 1;
+      if (ctx->piece_used[k]) {
+        e = hipEventSynchronize(ctx->piece_ev[k]);  // its previous content has left
+        if (e != hipSuccess) return fail("hipEventSynchronize", e);
+      }
+      tasks.clear();
+      uint64_t end = pos;
+      while (si < segs.size()) {
+        const uint64_t so = segs[si].off + within;
+        if (so - pos >= kStagePiece) break;
+        const uint64_t take = std::min<uint64_t>(segs[si].n - within, kStagePiece - (so - pos));
+        // (alignment gaps between segments are left as they are: nobody reads them)
+        tasks.push_back(CopyPool::Task{ctx->piece[k] + (so - pos), segs[si].src ? segs[si].src + within : nullptr, (size_t)take});
+        end = so + take;
+        within += take;
+        if (within == segs[si].n) {
+          si++;
+          within = 0;
+        } else {
+          break;  // the piece is full
+        }
+      }
+      ctx->copiers->copy_all(tasks);
+      e = hipMemcpyAsync(s->dev + pos, ctx->piece[k], end - pos, hipMemcpyHostToDevice, ctx->copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(ctx->piece_ev[k], ctx->copy_stream);
+      if (e != hipSuccess) return fail("hipMemcpyAsync", e);
+      ctx->piece_used[k] = true;
+    }
   }
-  hipError_t e = b.off ? hipMemcpyAsync(s->dev, ctx->pinned, b.off, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) {
-    set_err(ctx, "staging copy failed: %s", hipGetErrorString(e));
-    (void)hipFree(s->dev);
-    delete s;
-    return ORCGPU_HIP_ERROR;
-  }
+  e = hipEventRecord(s->ready, ctx->copy_stream);
+  if (e != hipSuccess) return fail("hipEventRecord", e);
   *out = s;
   return ORCGPU_OK;
 }
 
 void orcgpu_staged_free(orcgpu_staged* s) {
   if (!s) return;
-  if (s->dev) (void)hipFree(s->dev);
+  if (s->ready) {
+    (void)hipEventSynchronize(s->ready);  // a copy may still be writing the arena
+    (void)hipEventDestroy(s->ready);
+  }
+  if (s->dev) {
+    // back to the pool (decodes that used the stripe have returned: they end with a stream synchronisation)
+    orcgpu_ctx* c = s->ctx;
+    size_t pooled = 0;
+    for (auto& a : c->arena_pool) pooled += a.second;
+    if (c->arena_pool.size() < 64 && pooled + s->dev_cap <= (8ull << 30)) c->arena_pool.push_back({s->dev, s->dev_cap});
+    else (void)hipFree(s->dev);
+  }
   delete s;
 }
 uint64_t orcgpu_staged_bytes(const orcgpu_staged* s) { return s ? s->stream_bytes : 0; }
