@@ -164,6 +164,26 @@ int orcgpu_result_batch_view(const orcgpu_result* r, uint32_t batch, uint32_t co
 int orcgpu_result_copy_batch(orcgpu_ctx* ctx, const orcgpu_result* r, uint32_t batch, uint32_t column, void* values,
                              int32_t* offsets, void* validity);
 
+/* ---- row selection --------------------------------------------------------------------------------------- */
+/* One run of a RowSelection (src/row_selection.rs:32-52): row_count rows skipped or selected. */
+typedef struct {
+  uint64_t row_count;
+  int32_t skip;  /* nonzero: skip, zero: select */
+} orcgpu_row_selector;
+/* Applies the stripe's part of a RowSelection to a decoded stripe -- the `row_selection` argument of
+ * NaiveStripeDecoder::new_with_selection (src/array_decoder/mod.rs:570-594).  Afterwards the result's batches are the
+ * RecordBatches next_with_row_selection yields (mod.rs:302-365): one per select step of at most batch_size rows, in
+ * order; orcgpu_result_batches / _batch_view / _copy_batch / _export_batch speak in those batches.  The stripe was
+ * decoded whole (the reference's skip_values decodes and discards too, rle_v2/mod.rs:148-175); values and string bytes
+ * of a selected batch are used in place, its validity bitmap, Boolean bits and offsets are rebuilt on the device.
+ * Selectors are normalised like `From<Vec<RowSelector>>` (row_selection.rs:466-482). */
+int orcgpu_result_select(orcgpu_ctx* ctx, orcgpu_result* r, const orcgpu_row_selector* selectors, uint32_t n);
+/* Host only: the stepping by itself.  Splits the first stripe_rows rows off the selection (RowSelection::split_off,
+ * row_selection.rs:278-314), runs next_with_row_selection over them and reports the batches as row ranges of the stripe
+ * (starts / lens, at most cap of them; *n_out = how many there are) and what is left of the selection (rest). */
+int orcgpu_selection_batches(const orcgpu_row_selector* selectors, uint32_t n, uint64_t stripe_rows, uint32_t batch_size, uint64_t* starts,
+                             uint32_t* lens, uint32_t cap, uint32_t* n_out, orcgpu_row_selector* rest, uint32_t rest_cap, uint32_t* n_rest);
+
 /* Brings every Arrow buffer of the result to the host at once: one hipMemcpyAsync per result arena into pinned memory
  * (the counterpart of the reference handing out freshly allocated host buffers, array_decoder/mod.rs:100-120), one
  * synchronisation.  orcgpu_result_export_batch calls it on demand; the exported batches are views into that copy and
@@ -194,6 +214,9 @@ int orcgpu_reader_set_batch_size(orcgpu_reader* r, uint32_t batch_size);        
 int orcgpu_reader_set_projection(orcgpu_reader* r, const char* const* root_names, uint32_t n);       /* named_roots     */
 int orcgpu_reader_set_byte_range(orcgpu_reader* r, uint64_t start, uint64_t end);                    /* with_file_byte_range */
 int orcgpu_reader_set_timestamp_precision(orcgpu_reader* r, int arrow_target);                       /* ORCGPU_ARROW_TIMESTAMP_* */
+/* with_row_selection (arrow_reader.rs:113): a selection over the rows of the FILE; every stripe takes its share with
+ * RowSelection::split_off, and once no rows are left in the selection later stripes are read whole (arrow_reader.rs:296-308). */
+int orcgpu_reader_set_row_selection(orcgpu_reader* r, const orcgpu_row_selector* selectors, uint32_t n);
 uint64_t orcgpu_reader_total_rows(const orcgpu_reader* r);                                           /* total_row_count */
 uint32_t orcgpu_reader_stripe_count(const orcgpu_reader* r);
 uint32_t orcgpu_reader_column_count(orcgpu_reader* r);                                               /* projected flat columns */

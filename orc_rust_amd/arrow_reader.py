@@ -47,6 +47,12 @@ class ArrowReaderBuilder:
         self._ctx._check(self._ctx.L.orcgpu_reader_set_timestamp_precision(self._h, {"s": 1, "ms": 2, "us": 3, "ns": 4}[unit]))
         return self
 
+    def with_row_selection(self, selectors):
+        """RowSelection over the file's rows (arrow_reader.rs:113): selectors = [(row_count, skip)], i.e.
+        RowSelector::select(n) = (n, False), RowSelector::skip(n) = (n, True)."""
+        self._ctx._check(self._ctx.L.orcgpu_reader_set_row_selection(self._h, capi.selector_array(selectors), len(selectors)))
+        return self
+
     def total_row_count(self):
         return self._ctx.L.orcgpu_reader_total_rows(self._h)
 

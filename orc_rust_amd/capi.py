@@ -20,9 +20,9 @@ EXPORTS = [
     "orcgpu_open", "orcgpu_close", "orcgpu_last_error", "orcgpu_version", "orcgpu_stage_stripe", "orcgpu_staged_free",
     "orcgpu_staged_bytes", "orcgpu_decode_staged", "orcgpu_stripe_decode", "orcgpu_result_free", "orcgpu_result_status",
     "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
-    "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
+    "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
     "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
-    "orcgpu_reader_set_projection", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision",
+    "orcgpu_reader_set_projection", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection",
     "orcgpu_reader_total_rows", "orcgpu_reader_stripe_count", "orcgpu_reader_column_count", "orcgpu_reader_column_name",
     "orcgpu_reader_next_batch",
 ]
@@ -47,6 +47,32 @@ class StripeDesc(C.Structure):
     _fields_ = [("n_rows", C.c_uint64), ("compression", C.c_int32), ("block_size", C.c_uint64), ("ts_base_seconds", C.c_int64),
                 ("batch_size", C.c_uint32), ("n_streams", C.c_uint32), ("streams", C.POINTER(Stream)), ("n_columns", C.c_uint32),
                 ("columns", C.POINTER(Column))]
+
+
+class RowSelector(C.Structure):
+    _fields_ = [("row_count", C.c_uint64), ("skip", C.c_int32)]
+
+
+def selector_array(selectors):
+    """[(row_count, skip)] -> ctypes array of orcgpu_row_selector"""
+    arr = (RowSelector * max(1, len(selectors)))()
+    for i, (n, skip) in enumerate(selectors):
+        arr[i].row_count = n
+        arr[i].skip = 1 if skip else 0
+    return arr
+
+
+def selection_batches(selectors, stripe_rows, batch_size=8192):
+    """Host only: ([(start, len)] the selection yields on a stripe of stripe_rows rows, [(row_count, skip)] left for the next stripe)."""
+    L = load()
+    cap = len(selectors) + stripe_rows // max(1, batch_size) + 8
+    starts, lens = (C.c_uint64 * cap)(), (C.c_uint32 * cap)()
+    rest = (RowSelector * (len(selectors) + 2))()
+    n_out, n_rest = C.c_uint32(), C.c_uint32()
+    rc = L.orcgpu_selection_batches(selector_array(selectors), len(selectors), stripe_rows, batch_size, starts, lens, cap, C.byref(n_out), rest,
+                                    len(selectors) + 2, C.byref(n_rest))
+    assert rc == 0 and n_out.value <= cap
+    return [(starts[i], lens[i]) for i in range(n_out.value)], [(rest[i].row_count, bool(rest[i].skip)) for i in range(n_rest.value)]
 
 
 class BatchView(C.Structure):
@@ -91,6 +117,10 @@ def load():
     L.orcgpu_result_batch_view.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(BatchView)]
     L.orcgpu_result_copy_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orcgpu_result_fetch.argtypes = [C.c_void_p, C.c_void_p]
+    L.orcgpu_result_select.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RowSelector), C.c_uint32]
+    L.orcgpu_selection_batches.argtypes = [C.POINTER(RowSelector), C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                           C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(RowSelector), C.c_uint32, C.POINTER(C.c_uint32)]
+    L.orcgpu_reader_set_row_selection.argtypes = [C.c_void_p, C.POINTER(RowSelector), C.c_uint32]
     L.orcgpu_result_export_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.orcgpu_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.orcgpu_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
@@ -262,6 +292,10 @@ class Result:
             validity.ctypes.data if validity is not None else None))
         return {"status": 0, "length": n, "null_count": v.null_count, "validity": validity.tobytes() if validity is not None else None,
                 "values": values[:v.values_bytes].tobytes(), "offsets": offsets}
+
+    def select(self, selectors):
+        """Row selection over the decoded stripe: selectors = [(row_count, skip)] (orcgpu_result_select)."""
+        self.ctx._check(self.ctx.L.orcgpu_result_select(self.ctx.h, self.h, selector_array(selectors), len(selectors)))
 
     def fetch(self):
         """One device-to-host copy of all the result's Arrow buffers (pinned memory); export_batch then makes views."""

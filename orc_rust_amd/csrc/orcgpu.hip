@@ -34,6 +34,7 @@
 #include "device/column_kernels.hip"
 #include "device/string_kernels.hip"
 #include "device/decompress_kernels.hip"
+#include "device/select_kernels.hip"
 
 // Arrow C Data Interface structs (public, stable ABI)
 extern "C" {
@@ -290,6 +291,9 @@ struct ColumnOut {
   uint64_t validity_off = 0;                      // n_batches * words_per_batch u64
   std::vector<uint64_t> null_counts;              // host copy, per batch
   std::vector<uint64_t> char_base, char_total;    // strings: per batch, host copies
+  // row selection (orcgpu_result_select): per selected batch
+  uint64_t sel_validity_off = 0, sel_offsets_off = 0, sel_bool_off = 0;  // in orcgpu_result::sel_arena
+  std::vector<uint64_t> sel_nulls, sel_char_start, sel_char_total;
   // error bookkeeping (resolved after the summary copy)
   int status = 0;
   uint32_t err_batch = 0;
@@ -304,8 +308,11 @@ struct HostMirror {
   uint8_t* arena[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
   uint8_t* chars[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
   size_t arena_cap[kMaxLanes] = {0, 0, 0, 0}, chars_cap[kMaxLanes] = {0, 0, 0, 0};
+  uint8_t* sel = nullptr;  // per-batch buffers of a row selection
+  size_t sel_cap = 0;
   void unref() {
     if (refs.fetch_sub(1) == 1) {
+      if (sel) (void)hipHostFree(sel);
       for (auto p : arena)
         if (p) (void)hipHostFree(p);
       for (auto p : chars)
@@ -324,6 +331,14 @@ struct orcgpu_result {
   size_t arena_used[kMaxLanes] = {0, 0, 0, 0}, chars_used[kMaxLanes] = {0, 0, 0, 0};  // bytes of the last decode
   HostMirror* mirror = nullptr;  // filled by orcgpu_result_fetch
   bool mirror_valid = false;
+  // row selection: once orcgpu_result_select has run, batch b is rows [sel[b].start, sel[b].start + sel[b].len)
+  bool selected = false;
+  std::vector<SelBatch> sel;
+  DevBuf sel_arena;
+  size_t sel_used = 0;
+  uint32_t full_batches = 0;     // batches of the underlying uniform decode
+  int full_status = 0;           // status of the underlying decode (before the selection re-mapped the failing batch)
+  uint32_t full_err_batch = 0, full_err_col = 0;
   std::vector<ColumnOut> cols;
   int status = 0;
   uint32_t err_batch = 0, err_col = 0;
@@ -798,4 +813,5 @@ struct SummaryLayout {
 #include "orcgpu_ext.inc"
 #include "orcgpu_decode.inc"
 #include "orcgpu_export.inc"
+#include "orcgpu_select.inc"
 #include "orcgpu_reader.inc"
