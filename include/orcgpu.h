@@ -65,7 +65,17 @@ enum { ORCGPU_ENC_DIRECT = 0, ORCGPU_ENC_DICTIONARY = 1, ORCGPU_ENC_DIRECT_V2 = 
  * 0 picks the default mapping of src/schema.rs:503-579. */
 enum {
   ORCGPU_ARROW_DEFAULT = 0,
-  ORCGPU_ARROW_TIMESTAMP_S = 1, ORCGPU_ARROW_TIMESTAMP_MS = 2, ORCGPU_ARROW_TIMESTAMP_US = 3, ORCGPU_ARROW_TIMESTAMP_NS = 4
+  /* the default mapping at another time unit (with_timestamp_precision): Timestamp -> Timestamp(unit), TimestampInstant -> Timestamp(unit, "UTC") */
+  ORCGPU_ARROW_TIMESTAMP_S = 1, ORCGPU_ARROW_TIMESTAMP_MS = 2, ORCGPU_ARROW_TIMESTAMP_US = 3, ORCGPU_ARROW_TIMESTAMP_NS = 4,
+  /* an explicit Arrow type (with_schema): the pairs array_decoder_factory accepts decode, every other pair is
+   * ORCGPU_MISMATCHED_SCHEMA (mod.rs:390-511, timestamp.rs:149-232) */
+  ORCGPU_ARROW_BOOLEAN = 10, ORCGPU_ARROW_INT8 = 11, ORCGPU_ARROW_INT16 = 12, ORCGPU_ARROW_INT32 = 13, ORCGPU_ARROW_INT64 = 14,
+  ORCGPU_ARROW_FLOAT32 = 15, ORCGPU_ARROW_FLOAT64 = 16, ORCGPU_ARROW_UTF8 = 17, ORCGPU_ARROW_BINARY = 18, ORCGPU_ARROW_DATE32 = 19,
+  ORCGPU_ARROW_DECIMAL128 = 20,  /* precision / scale in arrow_precision / arrow_scale; (38, 9) is also the wide target of timestamps */
+  ORCGPU_ARROW_TIMESTAMP_S_UTC = 21, ORCGPU_ARROW_TIMESTAMP_MS_UTC = 22, ORCGPU_ARROW_TIMESTAMP_US_UTC = 23, ORCGPU_ARROW_TIMESTAMP_NS_UTC = 24,
+  ORCGPU_ARROW_TIMESTAMP_S_NOTZ = 31, ORCGPU_ARROW_TIMESTAMP_MS_NOTZ = 32, ORCGPU_ARROW_TIMESTAMP_US_NOTZ = 33, ORCGPU_ARROW_TIMESTAMP_NS_NOTZ = 34,
+  ORCGPU_ARROW_TIMESTAMP_OTHER_TZ = 35,  /* Timestamp(_, Some(tz)) with tz != "UTC": UnsupportedTypeVariant for TimestampInstant */
+  ORCGPU_ARROW_OTHER = 99        /* any Arrow type the path has no decoder for */
 };
 
 typedef struct orcgpu_ctx orcgpu_ctx;          /* one GPU, one HIP stream, reusable workspace */
@@ -93,6 +103,7 @@ typedef struct {
   uint32_t dictionary_size;  /* column.rs:40-45                              */
   uint32_t precision, scale; /* DECIMAL                                      */
   int32_t arrow_target;      /* ORCGPU_ARROW_*                               */
+  uint32_t arrow_precision, arrow_scale; /* ORCGPU_ARROW_DECIMAL128           */
 } orcgpu_column;
 
 typedef struct {
@@ -212,6 +223,12 @@ int orcgpu_reader_open_bytes(orcgpu_ctx* ctx, const uint8_t* data, uint64_t len,
 void orcgpu_reader_close(orcgpu_reader* r);
 int orcgpu_reader_set_batch_size(orcgpu_reader* r, uint32_t batch_size);                             /* with_batch_size */
 int orcgpu_reader_set_projection(orcgpu_reader* r, const char* const* root_names, uint32_t n);       /* named_roots     */
+int orcgpu_reader_set_projection_roots(orcgpu_reader* r, const uint32_t* root_indices, uint32_t n);  /* ProjectionMask::roots (projection.rs:37): indices of root columns */
+/* with_schema (arrow_reader.rs:80): the Arrow schema to decode into, as an Arrow C Data Interface struct ("+s") whose
+ * children are matched with the projected root columns by position (NaiveStripeDecoder::new zips columns and fields,
+ * array_decoder/mod.rs:577-582).  Field names become the batches' column names; a type pair the reference has no decoder
+ * for makes the first orcgpu_reader_next_batch return ORCGPU_MISMATCHED_SCHEMA.  The schema is read, not consumed. */
+int orcgpu_reader_set_schema(orcgpu_reader* r, const struct ArrowSchema* schema);
 int orcgpu_reader_set_byte_range(orcgpu_reader* r, uint64_t start, uint64_t end);                    /* with_file_byte_range */
 int orcgpu_reader_set_timestamp_precision(orcgpu_reader* r, int arrow_target);                       /* ORCGPU_ARROW_TIMESTAMP_* */
 /* with_row_selection (arrow_reader.rs:113): a selection over the rows of the FILE; every stripe takes its share with

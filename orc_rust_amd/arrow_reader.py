@@ -38,6 +38,24 @@ class ArrowReaderBuilder:
         self._ctx._check(self._ctx.L.orcgpu_reader_set_projection(self._h, arr, len(root_names)))
         return self
 
+    def with_projection_roots(self, indices):
+        """ProjectionMask::roots (projection.rs:37): root columns by index."""
+        arr = (C.c_uint32 * max(1, len(indices)))(*indices)
+        self._ctx._check(self._ctx.L.orcgpu_reader_set_projection_roots(self._h, arr, len(indices)))
+        return self
+
+    def with_schema(self, schema):
+        """with_schema (arrow_reader.rs:80): a pyarrow.Schema, handed over through the Arrow C Data Interface."""
+        buf = (C.c_uint8 * 72)()   # struct ArrowSchema
+        schema._export_to_c(C.addressof(buf))
+        try:
+            self._ctx._check(self._ctx.L.orcgpu_reader_set_schema(self._h, C.addressof(buf)))
+        finally:
+            release = C.cast(C.addressof(buf) + 56, C.POINTER(C.CFUNCTYPE(None, C.c_void_p)))[0]  # ArrowSchema::release
+            if release:
+                release(C.addressof(buf))
+        return self
+
     def with_file_byte_range(self, start, end):
         self._ctx._check(self._ctx.L.orcgpu_reader_set_byte_range(self._h, start, end))
         return self

@@ -22,7 +22,7 @@ EXPORTS = [
     "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
     "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
     "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
-    "orcgpu_reader_set_projection", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection",
+    "orcgpu_reader_set_projection", "orcgpu_reader_set_projection_roots", "orcgpu_reader_set_schema", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection",
     "orcgpu_reader_total_rows", "orcgpu_reader_stripe_count", "orcgpu_reader_column_count", "orcgpu_reader_column_name",
     "orcgpu_reader_next_batch",
 ]
@@ -40,7 +40,8 @@ class Stream(C.Structure):
 
 class Column(C.Structure):
     _fields_ = [("column_id", C.c_uint32), ("orc_type", C.c_int32), ("encoding", C.c_int32), ("dictionary_size", C.c_uint32),
-                ("precision", C.c_uint32), ("scale", C.c_uint32), ("arrow_target", C.c_int32)]
+                ("precision", C.c_uint32), ("scale", C.c_uint32), ("arrow_target", C.c_int32), ("arrow_precision", C.c_uint32),
+                ("arrow_scale", C.c_uint32)]
 
 
 class StripeDesc(C.Structure):
@@ -129,6 +130,8 @@ def load():
     L.orcgpu_reader_close.argtypes = [C.c_void_p]
     L.orcgpu_reader_set_batch_size.argtypes = [C.c_void_p, C.c_uint32]
     L.orcgpu_reader_set_projection.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32]
+    L.orcgpu_reader_set_projection_roots.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+    L.orcgpu_reader_set_schema.argtypes = [C.c_void_p, C.c_void_p]
     L.orcgpu_reader_set_byte_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
     L.orcgpu_reader_set_timestamp_precision.argtypes = [C.c_void_p, C.c_int]
     L.orcgpu_reader_total_rows.restype = C.c_uint64
@@ -193,6 +196,8 @@ class Context:
             carr[i].precision = c.get("precision", 0)
             carr[i].scale = c.get("scale", 0)
             carr[i].arrow_target = c.get("arrow_target", 0)
+            carr[i].arrow_precision = c.get("arrow_precision", 0)
+            carr[i].arrow_scale = c.get("arrow_scale", 0)
         d = StripeDesc(n_rows, COMP[compression] if isinstance(compression, str) else compression, block_size, ts_base, batch_size,
                        len(streams), sarr, len(columns), carr)
         out = C.c_void_p()

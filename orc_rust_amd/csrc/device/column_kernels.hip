@@ -315,6 +315,11 @@ extern "C" __global__ void __launch_bounds__(256) timestamp_kernel(const int64_t
     // division (which costs hundreds of instructions per row), constants per unit
     uint64_t qn, rem;
     int64_t m;
+    if (unit == 4) {
+      // Decimal128(38, 9) target: the raw nanoseconds as i128, nothing to lose or overflow (encoding/timestamp.rs:78-119)
+      reinterpret_cast<__int128*>(out)[i] = (__int128)s * 1000000000 + (__int128)nn;
+      return;
+    }
     if (unit == 3) {
       qn = nn, rem = 0, m = 1000000000;
     } else if (unit == 2) {
@@ -329,7 +334,8 @@ extern "C" __global__ void __launch_bounds__(256) timestamp_kernel(const int64_t
     if (bad) report_row(err, i, ORC_E_TIMESTAMP);
     r = (int64_t)q;
   }
-  out[i] = r;
+  if (unit == 4) reinterpret_cast<__int128*>(out)[i] = 0;  // null slot
+  else out[i] = r;
 }
 
 // Float/Double: read_exact of `needed` values must fit in the stream (float.rs:70-74 -> IoError).
