@@ -118,6 +118,11 @@ typedef struct {
   const orcgpu_stream* streams;
   uint32_t n_columns;
   const orcgpu_column* columns;
+  const char* writer_timezone; /* StripeFooter.writer_timezone (stripe.rs:167-171) or NULL.  When given it names a zone of the
+                              * system's tz database ($TZDIR, /usr/share/zoneinfo; ORCGPU_UNSUPPORTED if it is not there):
+                              * ts_base_seconds is then taken from it and TIMESTAMP columns are re-labelled from that zone
+                              * to UTC on the device (array_decoder/timestamp.rs:236-291; values chrono cannot hold become
+                              * nulls, as there).  TIMESTAMP_INSTANT columns ignore it. */
 } orcgpu_stripe_desc;
 
 /* ---- context ---------------------------------------------------------------------------------- */
@@ -189,6 +194,10 @@ typedef struct {
  * of a selected batch are used in place, its validity bitmap, Boolean bits and offsets are rebuilt on the device.
  * Selectors are normalised like `From<Vec<RowSelector>>` (row_selection.rs:466-482). */
 int orcgpu_result_select(orcgpu_ctx* ctx, orcgpu_result* r, const orcgpu_row_selector* selectors, uint32_t n);
+/* Host only: the UTC offsets (seconds east of Greenwich) the library uses for a writer time zone at n instants (seconds since
+ * the UNIX epoch), and the ORC epoch in that zone (2015-01-01T00:00:00 there, timestamp.rs:133-147; orc_epoch may be NULL).
+ * ORCGPU_UNSUPPORTED when the tz database does not have the zone. */
+int orcgpu_timezone_offsets(const char* name, const int64_t* instants, uint32_t n, int32_t* offsets, int64_t* orc_epoch);
 /* Host only: the stepping by itself.  Splits the first stripe_rows rows off the selection (RowSelection::split_off,
  * row_selection.rs:278-314), runs next_with_row_selection over them and reports the batches as row ranges of the stripe
  * (starts / lens, at most cap of them; *n_out = how many there are) and what is left of the selection (rest). */

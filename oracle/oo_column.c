@@ -495,3 +495,69 @@ int oo_column_next_batch(oo_column* c, uint64_t batch_size, oo_batch* out) {
   free(bools);
   return out->status = OO_UNSUPPORTED;
 }
+
+/* ---- writer time zone (array_decoder/timestamp.rs:236-291, :316-349) ------------------------------------ */
+static int32_t tz_offset(const int64_t* at, const int32_t* offs, uint32_t n_at, int32_t offs0, int64_t sec) {
+  /* chrono-tz: the span whose start is <= the instant (binary search over the zone's timespans) */
+  uint32_t lo = 0, hi = n_at;
+  while (lo < hi) {
+    uint32_t mid = lo + (hi - lo) / 2;
+    if (at[mid] <= sec) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo ? offs[lo - 1] : offs0;
+}
+
+static int64_t floor_div(int64_t a, int64_t b) {
+  int64_t q = a / b;
+  return (a % b < 0) ? q - 1 : q;
+}
+
+uint64_t oo_timestamps_to_utc(int64_t* values, const uint8_t* validity, uint64_t n, int unit, const int64_t* at, const int32_t* offs,
+                              uint32_t n_at, int32_t offs0, uint8_t* validity_out) {
+  /* DateTime::<Utc>::MIN_UTC / MAX_UTC = NaiveDate::MIN (-262143-01-01) 00:00:00 / NaiveDate::MAX (+262142-12-31) 23:59:59.999999999 */
+  const int64_t chrono_min = -8334601315200ll, chrono_max = 8210266876799ll;
+  uint64_t nulls = 0;
+  memset(validity_out, 0, (n + 7) / 8);
+  for (uint64_t i = 0; i < n; i++) {
+    if (validity && !((validity[i >> 3] >> (i & 7)) & 1)) {
+      nulls++;
+      continue; /* try_unary / unary_opt only visit valid slots */
+    }
+    int64_t ts = values[i], out = 0;
+    int ok;
+    if (unit == 3) {
+      /* writer_tz.timestamp_nanos(ts).naive_local().and_utc().timestamp_nanos_opt() */
+      int64_t sec = floor_div(ts, 1000000000);
+      __int128 r = (__int128)ts + (__int128)tz_offset(at, offs, n_at, offs0, sec) * 1000000000;
+      ok = r <= (__int128)INT64_MAX && r >= (__int128)INT64_MIN;
+      out = (int64_t)r;
+    } else {
+      /* writer_tz.timestamp_micros(ts * k).single().map(|dt| dt.naive_local().and_utc().timestamp_micros() / k) */
+      int64_t k = unit == 0 ? 1000000 : (unit == 1 ? 1000 : 1);
+      int64_t m = (int64_t)((uint64_t)ts * (uint64_t)k); /* release build: wrapping */
+      int64_t sec = floor_div(m, 1000000);
+      ok = sec >= chrono_min && sec <= chrono_max;
+      if (ok) out = (m + (int64_t)tz_offset(at, offs, n_at, offs0, sec) * 1000000) / k;
+    }
+    if (ok) {
+      values[i] = out;
+      validity_out[i >> 3] |= (uint8_t)(1u << (i & 7));
+    } else {
+      values[i] = 0;
+      nulls++;
+    }
+  }
+  return nulls;
+}
+
+void oo_timestamp_decimals_to_utc(uint64_t* values, uint64_t n, const int64_t* at, const int32_t* offs, uint32_t n_at, int32_t offs0) {
+  for (uint64_t i = 0; i < n; i++) {
+    __int128 ts = (__int128)(((unsigned __int128)values[2 * i + 1] << 64) | values[2 * i]);
+    __int128 q = ts / 1000000000;
+    if (ts % 1000000000 < 0) q--; /* div_euclid */
+    __int128 r = ts + (__int128)tz_offset(at, offs, n_at, offs0, (int64_t)q) * 1000000000;
+    values[2 * i] = (uint64_t)(unsigned __int128)r;
+    values[2 * i + 1] = (uint64_t)((unsigned __int128)r >> 64);
+  }
+}

@@ -20,7 +20,7 @@ EXPORTS = [
     "orcgpu_open", "orcgpu_close", "orcgpu_last_error", "orcgpu_version", "orcgpu_stage_stripe", "orcgpu_staged_free",
     "orcgpu_staged_bytes", "orcgpu_decode_staged", "orcgpu_stripe_decode", "orcgpu_result_free", "orcgpu_result_status",
     "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
-    "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
+    "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_timezone_offsets", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
     "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
     "orcgpu_reader_set_projection", "orcgpu_reader_set_projection_roots", "orcgpu_reader_set_schema", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection",
     "orcgpu_reader_total_rows", "orcgpu_reader_stripe_count", "orcgpu_reader_column_count", "orcgpu_reader_column_name",
@@ -47,7 +47,7 @@ class Column(C.Structure):
 class StripeDesc(C.Structure):
     _fields_ = [("n_rows", C.c_uint64), ("compression", C.c_int32), ("block_size", C.c_uint64), ("ts_base_seconds", C.c_int64),
                 ("batch_size", C.c_uint32), ("n_streams", C.c_uint32), ("streams", C.POINTER(Stream)), ("n_columns", C.c_uint32),
-                ("columns", C.POINTER(Column))]
+                ("columns", C.POINTER(Column)), ("writer_timezone", C.c_char_p)]
 
 
 class RowSelector(C.Structure):
@@ -76,6 +76,18 @@ def selection_batches(selectors, stripe_rows, batch_size=8192):
     return [(starts[i], lens[i]) for i in range(n_out.value)], [(rest[i].row_count, bool(rest[i].skip)) for i in range(n_rest.value)]
 
 
+def timezone_offsets(name, instants):
+    """Host only: (UTC offsets in seconds of zone `name` at the given UNIX instants, the ORC epoch in that zone)."""
+    L = load()
+    a = np.ascontiguousarray(instants, dtype=np.int64)
+    out = np.zeros(len(a), dtype=np.int32)
+    epoch = C.c_int64()
+    rc = L.orcgpu_timezone_offsets(name.encode(), a.ctypes.data_as(C.c_void_p), len(a), out.ctypes.data_as(C.c_void_p), C.byref(epoch))
+    if rc:
+        raise OrcGpuError(rc, "time zone %r" % name)
+    return out, epoch.value
+
+
 class BatchView(C.Structure):
     _fields_ = [("length", C.c_uint64), ("null_count", C.c_uint64), ("validity", C.c_void_p), ("values", C.c_void_p),
                 ("values_bytes", C.c_uint64), ("offsets", C.c_void_p)]
@@ -94,6 +106,13 @@ def load():
     if _lib is not None:
         return _lib
     so = os.environ.get("ORCGPU_LIB") or _build.build()
+    if "TZDIR" not in os.environ and not os.path.isdir("/usr/share/zoneinfo"):
+        # writer time zones are resolved by the library through the system's tz database; without one, use the tzdata package's
+        try:
+            import tzdata
+            os.environ["TZDIR"] = os.path.join(os.path.dirname(tzdata.__file__), "zoneinfo")
+        except ImportError:
+            pass
     L = C.CDLL(so)
     L.orcgpu_open.restype = C.c_void_p
     L.orcgpu_open.argtypes = [C.c_int, C.c_void_p]
@@ -174,7 +193,7 @@ class Context:
         if rc:
             raise OrcGpuError(rc, self.error())
 
-    def stage(self, n_rows, streams, columns, compression="none", block_size=262144, batch_size=8192, ts_base=0):
+    def stage(self, n_rows, streams, columns, compression="none", block_size=262144, batch_size=8192, ts_base=0, writer_timezone=None):
         """streams: [(column_id, kind, bytes)], columns: [dict(column_id, orc_type, encoding, dictionary_size, precision, scale, arrow_target)]"""
         keep = [bytes(b) if not isinstance(b, (bytes, np.ndarray)) else b for _, _, b in streams]
         sarr = (Stream * max(1, len(streams)))()
@@ -199,7 +218,7 @@ class Context:
             carr[i].arrow_precision = c.get("arrow_precision", 0)
             carr[i].arrow_scale = c.get("arrow_scale", 0)
         d = StripeDesc(n_rows, COMP[compression] if isinstance(compression, str) else compression, block_size, ts_base, batch_size,
-                       len(streams), sarr, len(columns), carr)
+                       len(streams), sarr, len(columns), carr, writer_timezone.encode() if writer_timezone else None)
         out = C.c_void_p()
         self._check(self.L.orcgpu_stage_stripe(self.h, C.byref(d), C.byref(out)))
         return Staged(self, out.value)

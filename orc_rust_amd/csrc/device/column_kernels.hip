@@ -345,3 +345,88 @@ extern "C" __global__ void float_check_kernel(const uint64_t* scalars, uint32_t 
     if (have < scalars[needed_idx]) atomicMin((unsigned long long*)err, ((unsigned long long)have << 8) | ORC_E_IO);
   }
 }
+
+// Writer time zone -> UTC re-labelling of decoded TIMESTAMP values (array_decoder/timestamp.rs:236-291, :316-349): the instant
+// is looked at in the writer's zone and its wall clock read as UTC, i.e. out = ts + offset(ts) with the zone's UTC offset at
+// that instant (table of transitions, binary search).  Per unit, as the release build of the reference computes it:
+//   s / ms / us  m = ts * k microseconds (wrapping); chrono must hold the instant (years -262143 ..= 262142) or the value
+//                becomes a null (try_unary fails -> unary_opt); out = (m + offset * 1e6) / k, truncating.
+//   ns           out = ts + offset * 1e9, a null when that leaves i64 (timestamp_nanos_opt).
+//   Decimal128   i128 nanoseconds + offset * 1e9 (no nulls).
+// A null clears the row's validity bit and raises the batch's null count; the validity words exist for every column that gets
+// here (all ones when the column has no PRESENT stream).
+struct TzJob {
+  void* values;
+  const unsigned long long* vbits;   // stripe-wide PRESENT bitmap or null
+  unsigned long long* validity;      // per batch
+  unsigned long long* null_counts;
+  const long long* at;
+  const int* offs;
+  uint64_t n_rows;
+  uint32_t n_at;
+  int offs0;
+  int unit;                          // 0 s, 1 ms, 2 us, 3 ns, 4 Decimal128(38, 9)
+  uint32_t batch, words_per_batch, pad;
+};
+
+__device__ __forceinline__ int tz_offset_at(const TzJob& j, long long sec) {
+  uint32_t lo = 0, hi = j.n_at;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (j.at[mid] <= sec) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo ? j.offs[lo - 1] : j.offs0;
+}
+
+extern "C" __global__ void __launch_bounds__(256) tz_shift_kernel(TzJob j) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= j.n_rows) return;
+  if (j.vbits && !((j.vbits[i >> 6] >> (i & 63)) & 1)) return;  // null row: stays 0
+  bool ok = true;
+  if (j.unit == 4) {
+    __int128* v = reinterpret_cast<__int128*>(j.values) + i;
+    const __int128 ts = *v;
+    __int128 q = ts / 1000000000;
+    if (ts % 1000000000 < 0) q--;
+    *v = ts + (__int128)tz_offset_at(j, (long long)q) * 1000000000;
+    return;
+  }
+  long long* v = reinterpret_cast<long long*>(j.values) + i;
+  const long long ts = *v;
+  if (j.unit == 3) {
+    long long sec = ts / 1000000000;
+    if (ts % 1000000000 < 0) sec--;
+    const __int128 r = (__int128)ts + (__int128)tz_offset_at(j, sec) * 1000000000;
+    ok = r <= (__int128)INT64_MAX && r >= (__int128)INT64_MIN;
+    if (ok) *v = (long long)r;
+  } else {
+    const long long k = j.unit == 0 ? 1000000 : (j.unit == 1 ? 1000 : 1);
+    const long long m = (long long)((unsigned long long)ts * (unsigned long long)k);
+    long long sec = m / 1000000;
+    if (m % 1000000 < 0) sec--;
+    // chrono's NaiveDate::MIN = -262143-01-01 and MAX = +262142-12-31
+    ok = sec >= -8334601315200ll && sec <= 8210266876799ll;
+    if (ok) *v = (m + (long long)tz_offset_at(j, sec) * 1000000) / k;
+  }
+  if (!ok) {
+    *v = 0;
+    const uint64_t b = i / j.batch, l = i % j.batch;
+    atomicAnd(&j.validity[b * j.words_per_batch + (l >> 6)], ~(1ull << (l & 63)));
+    atomicAdd(&j.null_counts[b], 1ull);
+  }
+}
+
+// all-ones validity words for a column without PRESENT whose values may still turn into nulls (tz_shift_kernel)
+extern "C" __global__ void __launch_bounds__(256) validity_ones_kernel(unsigned long long* validity, uint64_t n_rows, uint32_t batch, uint32_t words_per_batch,
+                                                                        uint64_t n_words) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_words) return;
+  const uint64_t b = t / words_per_batch, w = t % words_per_batch;
+  const uint64_t row0 = b * batch + w * 64;
+  uint64_t bend = (b + 1) * (uint64_t)batch;
+  if (bend > n_rows) bend = n_rows;
+  unsigned long long v = 0;
+  if (row0 < bend) v = bend - row0 >= 64 ? ~0ull : (1ull << (bend - row0)) - 1;
+  validity[t] = v;
+}

@@ -18,6 +18,8 @@
 #include <chrono>
 #include <atomic>
 #include <condition_variable>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <cstdarg>
@@ -117,6 +119,7 @@ struct ChunkInfo {
 }  // namespace
 
 #include "orcgpu_zstd_host.inc"
+#include "orcgpu_tz.inc"
 
 namespace {
 struct StagedStream {
@@ -244,6 +247,13 @@ struct orcgpu_ctx {
   int piece_next = 0;
   std::vector<std::pair<uint8_t*, size_t>> arena_pool;  // freed staged arenas (device pointer, bytes)
   struct CopyPool* copiers = nullptr;
+  // writer time zones seen so far (lane 0 only): host table + its copy in HBM ({at[n] i64}{offs[n] i32})
+  struct Zone {
+    TzTable table;
+    uint8_t* dev = nullptr;
+    int64_t epoch = 1420070400;
+  };
+  std::map<std::string, std::shared_ptr<Zone>> zones;
   bool ensure_pinned(size_t n) {
     if (n <= pinned_cap) return true;
     if (pinned) (void)hipHostFree(pinned);
@@ -265,6 +275,7 @@ struct orcgpu_staged {
   size_t dev_bytes = 0;     // bytes in use
   size_t dev_cap = 0;       // bytes of the arena (it may come from the pool)
   hipEvent_t ready = nullptr;  // recorded on the copy stream behind the stripe's last piece
+  std::shared_ptr<orcgpu_ctx::Zone> zone;  // writer time zone of the stripe (null: none given)
   uint64_t stream_bytes = 0;
   const StagedStream* find(uint32_t col, int kind) const {
     for (auto& s : streams)
@@ -484,6 +495,7 @@ struct ColPlan {
   orcgpu_column c;
   uint64_t n_rows;
   bool has_present = false;
+  bool tz = false;            // TIMESTAMP of a stripe with a writer time zone: re-labelled to UTC, which can yield nulls
   PlainStream present, data, length, secondary, dict;
   // scratch
   uint64_t pbytes_off = 0, vbits_off = 0, wpop_off = 0, rank_off = 0, rank_tiles_off = 0;
@@ -571,6 +583,8 @@ void orcgpu_close(orcgpu_ctx* c) {
     if (c->piece_ev[k]) (void)hipEventDestroy(c->piece_ev[k]);
   }
   for (auto& a : c->arena_pool) (void)hipFree(a.first);
+  for (auto& z : c->zones)
+    if (z.second->dev) (void)hipFree(z.second->dev);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->pinned) (void)hipHostFree(c->pinned);
   for (auto& e : c->ev)
@@ -601,6 +615,34 @@ int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_sta
   if (!s->desc.block_size) s->desc.block_size = 262144;
   if (!s->desc.batch_size) s->desc.batch_size = 8192;
   if (!s->desc.ts_base_seconds) s->desc.ts_base_seconds = 1420070400;
+  s->desc.writer_timezone = nullptr;
+  if (d->writer_timezone && d->writer_timezone[0]) {
+    // Stripe::writer_tz (stripe.rs:167-171): the ORC epoch is midnight 2015-01-01 in that zone (timestamp.rs:133-147)
+    const std::string name = d->writer_timezone;
+    auto it = ctx->zones.find(name);
+    if (it == ctx->zones.end()) {
+      auto z = std::make_shared<orcgpu_ctx::Zone>();
+      if (!find_timezone(name, z->table)) {
+        set_err(ctx, "writer timezone '%s': not found in the tz database (TZDIR, /usr/share/zoneinfo)", name.c_str());
+        delete s;
+        return ORCGPU_UNSUPPORTED;
+      }
+      z->epoch = tz_orc_epoch(z->table);
+      const size_t n = z->table.at.size();
+      if (hipMalloc((void**)&z->dev, n * 12 + 16) != hipSuccess) {
+        set_err(ctx, "hipMalloc for the table of time zone '%s' failed", name.c_str());
+        delete s;
+        return ORCGPU_HIP_ERROR;
+      }
+      if (n) {
+        HIP_TRY(ctx, hipMemcpy(z->dev, z->table.at.data(), n * 8, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(z->dev + n * 8, z->table.offs.data(), n * 4, hipMemcpyHostToDevice));
+      }
+      it = ctx->zones.emplace(name, z).first;
+    }
+    s->zone = it->second;
+    s->desc.ts_base_seconds = s->zone->epoch;
+  }
   s->cols.assign(d->columns, d->columns + d->n_columns);
   s->desc.columns = nullptr;
   s->desc.streams = nullptr;

@@ -16,27 +16,34 @@ def ctx():
     return _ctx
 
 
-def gpu_decode(n_rows, columns, streams, compression="none", block_size=262144, batch_size=8192, ts_base=0):
+def gpu_decode(n_rows, columns, streams, compression="none", block_size=262144, batch_size=8192, ts_base=0, writer_timezone=None):
     """columns: [dict(column_id, orc_type, encoding, ...)], streams: [(column_id, kind, bytes)]"""
     c = ctx()
-    staged = c.stage(n_rows, streams, columns, compression=compression, block_size=block_size, batch_size=batch_size, ts_base=ts_base)
+    staged = c.stage(n_rows, streams, columns, compression=compression, block_size=block_size, batch_size=batch_size, ts_base=ts_base,
+                     writer_timezone=writer_timezone)
     res = c.decode([staged])[0]
     staged.free()
     return res
 
 
-def oracle_column(col, streams, compression="none", block_size=262144, ts_unit=3, ts_base=1420070400):
+def oracle_column(col, streams, compression="none", block_size=262144, ts_unit=3, ts_base=1420070400, writer_timezone=None):
     sd = {k: (b.tobytes() if isinstance(b, np.ndarray) else bytes(b)) for cid, k, b in streams if cid == col["column_id"]}
+    tz = None
+    if writer_timezone and col["orc_type"] == 9:
+        # Stripe::writer_tz -> base epoch in that zone + TimestampOffsetArrayDecoder (timestamp.rs:128-147, :236-291)
+        import tz_table
+        tz = tz_table.table(writer_timezone)
+        ts_base = tz_table.orc_epoch(writer_timezone)
     return O.Column(col["orc_type"], col.get("encoding", 2), sd, dictionary_size=col.get("dictionary_size", 0),
                     precision=col.get("precision", 0), scale=col.get("scale", 0), ts_unit=ts_unit, ts_base=ts_base,
-                    compression=compression, block_size=block_size)
+                    compression=compression, block_size=block_size, tz=tz)
 
 
 def assert_column_parity(res, ci, col, streams, n_rows, batch_size, compression="none", block_size=262144, ts_unit=3,
-                         ts_base=1420070400, what=""):
+                         ts_base=1420070400, what="", writer_timezone=None):
     """The reference yields Ok batches until the first failing one (arrow_reader.rs:333-346): the
     GPU result must agree on every Ok batch bit for bit and on the index + kind of the failure."""
-    oc = oracle_column(col, streams, compression, block_size, ts_unit, ts_base)
+    oc = oracle_column(col, streams, compression, block_size, ts_unit, ts_base, writer_timezone)
     gst, gbatch, gcol = res.status()
     left = n_rows
     b = 0

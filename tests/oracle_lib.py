@@ -82,6 +82,10 @@ def lib():
         L.oo_column_new.argtypes = [C.POINTER(ColumnDesc), C.POINTER(C.c_int)]
         L.oo_column_next_batch.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Batch)]
         L.oo_column_free.argtypes = [C.c_void_p]
+        L.oo_timestamps_to_utc.restype = C.c_uint64
+        L.oo_timestamps_to_utc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
+        L.oo_timestamp_decimals_to_utc.restype = None
+        L.oo_timestamp_decimals_to_utc.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32]
         _lib = L
     return _lib
 
@@ -191,12 +195,30 @@ def fix_scale(value, fixed_scale, varying_scale):
 _WIDTH = {1: 1, 2: 2, 3: 4, 15: 4, 5: 4, 4: 8, 6: 8, 9: 8, 18: 8, 14: 16}
 
 
+def timestamps_to_utc(res, n, unit, tz):
+    """TimestampOffsetArrayDecoder over one decoded batch `res` (oo_timestamps_to_utc)."""
+    at = np.ascontiguousarray(tz[0], dtype=np.int64)
+    offs = np.ascontiguousarray(tz[1], dtype=np.int32)
+    vals = np.frombuffer(res["values"], dtype=np.int64).copy()
+    vout = np.zeros((n + 7) // 8, dtype=np.uint8)
+    vin = res["validity"]
+    nulls = lib().oo_timestamps_to_utc(vals.ctypes.data, vin, n, unit, at.ctypes.data, offs.ctypes.data, len(at), int(tz[2]), vout.ctypes.data)
+    out = dict(res)
+    out["values"] = vals.tobytes()
+    out["null_count"] = nulls
+    out["validity"] = vout.tobytes() if nulls else None
+    return out
+
+
 class Column:
     """Batch-by-batch oracle column decoder (oo_column_*).  `streams` maps Stream.Kind -> bytes."""
 
     def __init__(self, orc_type, encoding, streams, dictionary_size=0, precision=0, scale=0, ts_unit=3,
-                 ts_base=1420070400, compression="none", block_size=262144):
+                 ts_base=1420070400, compression="none", block_size=262144, tz=None):
+        """tz: (at int64[], offs int32[], offs0) -- the writer's zone; TIMESTAMP batches are then re-labelled to UTC."""
         L = lib()
+        self.tz = tz if orc_type == 9 else None
+        self.ts_unit = ts_unit
         self._keep = [bytes(v) for v in streams.values()]
         arr = (Stream * max(len(streams), 1))()
         for i, (k, v) in enumerate(zip(streams.keys(), self._keep)):
@@ -223,6 +245,8 @@ class Column:
             res["values"] = C.string_at(b.values, b.values_len) if b.values_len else b""
         if b.offsets:
             res["offsets"] = np.frombuffer(C.string_at(b.offsets, 4 * (n + 1)), dtype=np.int32).copy()
+        if self.tz is not None and n:
+            res = timestamps_to_utc(res, n, self.ts_unit, self.tz)
         return res
 
     def close(self):

@@ -200,7 +200,13 @@ class OrcFile:
     def oracle_column(self, stripe, column_id, ts_unit=3, ts_base=None):
         t = self.types[column_id]
         enc, dsz = stripe.encodings[column_id] if column_id < len(stripe.encodings) else (0, 0)
+        tz = None
         if ts_base is None:
             ts_base = 1420070400
+            if stripe.writer_timezone and t.kind == 9:
+                # Stripe::writer_tz (stripe.rs:167-171): base epoch in that zone, batches re-labelled to UTC
+                import tz_table
+                ts_base = tz_table.orc_epoch(stripe.writer_timezone)
+                tz = tz_table.table(stripe.writer_timezone)
         return O.Column(t.kind, enc, self.column_streams(stripe, column_id), dictionary_size=dsz, precision=t.precision, scale=t.scale,
-                        ts_unit=ts_unit, ts_base=ts_base, compression=self.compression_name, block_size=self.block_size)
+                        ts_unit=ts_unit, ts_base=ts_base, compression=self.compression_name, block_size=self.block_size, tz=tz)

@@ -11,8 +11,6 @@ import orcfile
 
 pytestmark = pytest.mark.gpu
 
-UTC_ZONES = (None, "UTC", "GMT", "Etc/UTC", "Etc/GMT")
-
 
 def stripe_inputs(f, s):
     cols, streams = [], []
@@ -36,16 +34,18 @@ def test_gpu_matches_oracle_on_fixture(name):
             continue
         cols, streams = stripe_inputs(f, s)
         for batch in ((8192,) if big else (8192, 1000)):
-            res = G.gpu_decode(s.number_of_rows, cols, streams, compression=f.compression_name, block_size=f.block_size, batch_size=batch)
+            res = G.gpu_decode(s.number_of_rows, cols, streams, compression=f.compression_name, block_size=f.block_size, batch_size=batch,
+                               writer_timezone=s.writer_timezone)
             for ci, c in enumerate(cols):
                 G.assert_column_parity(res, ci, c, streams, s.number_of_rows, batch, compression=f.compression_name, block_size=f.block_size,
-                                       what=(name, si, c["name"], batch))
+                                       what=(name, si, c["name"], batch), writer_timezone=s.writer_timezone)
             res.free()
         if big and si >= 3:
             break
 
 
-@pytest.mark.parametrize("name", ["test.orc", "alltypes.none.orc", "TestOrcFile.testSnappy.orc", "TestVectorOrcFile.testLz4.orc", "decimal.orc"])
+@pytest.mark.parametrize("name", ["test.orc", "alltypes.none.orc", "TestOrcFile.testSnappy.orc", "TestVectorOrcFile.testLz4.orc", "decimal.orc",
+                                  "TestOrcFile.testDate1900.orc", "orc_split_elim_new.orc"])
 def test_arrow_c_data_export_equals_expectation(name):
     """Arrow C Data Interface export -> pyarrow: logical equality with the committed expectation."""
     import pyarrow as pa
@@ -55,9 +55,8 @@ def test_arrow_c_data_export_equals_expectation(name):
     names = None
     for s in f.stripes:
         cols, streams = stripe_inputs(f, s)
-        cols = [c for c in cols if not (c["orc_type"] == 9 and s.writer_timezone not in UTC_ZONES)]
         names = [c["name"] for c in cols]
-        res = G.gpu_decode(s.number_of_rows, cols, streams, compression=f.compression_name, block_size=f.block_size)
+        res = G.gpu_decode(s.number_of_rows, cols, streams, compression=f.compression_name, block_size=f.block_size, writer_timezone=s.writer_timezone)
         assert res.status()[0] == 0
         for b in range(res.n_batches):
             batches.append(res.export_batch(b))

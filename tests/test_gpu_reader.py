@@ -25,15 +25,14 @@ def ctx():
 
 def flat_names(path):
     f = orcfile.OrcFile(path)
-    non_utc = any(s.writer_timezone not in UTC_ZONES for s in f.stripes)
-    return [n for n, c, t in f.flat_columns() if not (t.kind == 9 and non_utc)], f
+    return [n for n, c, t in f.flat_columns()], f
 
 
 FILES = ["test.orc", "alltypes.none.orc", "alltypes.snappy.orc", "alltypes.zlib.orc", "alltypes.zstd.orc", "alltypes.lz4.orc",
          "string_long_long.orc", "string_dict_gzip.orc", "long_bool_gzip.orc", "patched_int.orc", "test_bigint.orc",
          "TestOrcFile.testSnappy.orc", "TestOrcFile.testWithoutIndex.orc", "TestVectorOrcFile.testLz4.orc",
          "TestVectorOrcFile.testZstd.0.12.orc", "decimal.orc", "nulls-at-end-snappy.orc", "TestOrcFile.testSeek.orc",
-         "TestOrcFile.test1.orc", "orc_split_elim_new.orc", "over1k_bloom.orc", "demo-12-zlib.orc"]
+         "TestOrcFile.test1.orc", "orc_split_elim_new.orc", "TestOrcFile.testDate1900.orc", "over1k_bloom.orc", "demo-12-zlib.orc"]
 
 
 @pytest.mark.parametrize("name", FILES)

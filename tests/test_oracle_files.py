@@ -9,8 +9,6 @@ import arrow_util as A
 import orcfile
 import oracle_lib as O
 
-UTC_ZONES = (None, "UTC", "GMT", "Etc/UTC", "Etc/GMT")
-
 
 def decode_column(f, col_id, typ, batch_size):
     chunks = []
@@ -38,8 +36,6 @@ def test_oracle_matches_golden(name):
     big = f.number_of_rows > 500_000
     checked = 0
     for cname, cid, typ in f.flat_columns():
-        if typ.kind in (9,) and any(s.writer_timezone not in UTC_ZONES for s in f.stripes):
-            continue  # non-UTC writer timezone conversion is a host post-pass, out of scope
         for batch_size in ((8192,) if big else (8192, 1000, 7)):
             chunks = decode_column(f, cid, typ, batch_size)
             want = expected.column(cname)
