@@ -638,6 +638,7 @@ __device__ __forceinline__ int lz4_wave(const uint8_t* src, uint32_t n, uint8_t*
 #include "inflate_device.h"
 #include "zstd_device.h"
 #include "zstd_entropy.h"
+#include "lz_parse.h"
 #include "lz_exec.h"
 
 // One kernel per codec family (a single kernel with all of them inlined runs out of scalar registers and
