@@ -218,6 +218,18 @@ __device__ __forceinline__ void lz_parse_chunk(LzpLds& L, ChunkDesc* cd, const C
         top[i] = in ? t : top[i];
       }
     }
+    // ... and through the whole block for the entries in its first window (where the chain comes in unless an element longer
+    // than 64 bytes straddles the border): one lookup on the critical path instead of one per window
+    uint32_t bx = top[0], bc = cnt[0];
+#pragma unroll
+    for (int i = 1; i < LZP_WIN; i++) {
+      const bool in = bx - 64u * i < 64u;  // (a stop flag is >= 2^31)
+      const int idx = (int)(((bx - 64u * i) & 63u) << 2);
+      const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)top[i]);
+      const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)cnt[i]);
+      bc += in ? c : 0u;
+      bx = in ? ((t & LZP_STOP) ? t : 64u * i + t) : bx;
+    }
     PROF_MARK(0);
     // ---- where does the chain come in? ----
     uint32_t e = bstart, base = 0;
@@ -234,13 +246,20 @@ __device__ __forceinline__ void lz_parse_chunk(LzpLds& L, ChunkDesc* cd, const C
     uint32_t out_pos = e, stop = 0, nrec = 0;
     if (e != LZP_END_POS) {
       uint32_t cur = e - bstart;  // >= LZP_BLK: the chain jumps over this block
+      if (cur < 64u) {
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)bx, (int)cur);
+        nrec = (uint32_t)__builtin_amdgcn_readlane((int)bc, (int)cur);
+        if (x & LZP_STOP) stop = x & 3;
+        else cur = x;
+      } else {
 #pragma unroll
-      for (int i = 0; i < LZP_WIN; i++) {
-        if (!stop && cur < 64u * (i + 1)) {
-          const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)top[i], (int)(cur - 64u * i));
-          nrec += (uint32_t)__builtin_amdgcn_readlane((int)cnt[i], (int)(cur - 64u * i));
-          if (x & LZP_STOP) stop = x & 3;
-          else cur = 64u * i + x;
+        for (int i = 1; i < LZP_WIN; i++) {
+          if (!stop && cur < 64u * (i + 1)) {
+            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)top[i], (int)(cur - 64u * i));
+            nrec += (uint32_t)__builtin_amdgcn_readlane((int)cnt[i], (int)(cur - 64u * i));
+            if (x & LZP_STOP) stop = x & 3;
+            else cur = 64u * i + x;
+          }
         }
       }
       out_pos = stop ? LZP_END_POS : bstart + cur;
@@ -268,7 +287,10 @@ __device__ __forceinline__ void lz_parse_chunk(LzpLds& L, ChunkDesc* cd, const C
         }
       }
     }
-    // ---- which positions the chain visits (off the critical path: the blocks behind are already on their way) ----
+    // ---- which positions the chain visits (off the critical path: the blocks behind are already on their way).  A window
+    // with few elements is walked (one cross-lane read per element); a dense one is marked by all lanes at once: with the
+    // jump tables J_k (2^k elements ahead) and D (elements up to the window's end), position p is on the chain from e
+    // iff it leaves the window where e does and J^(D(e) - D(p))(e) = p ----
     unsigned long long mem[LZP_WIN];
 #pragma unroll
     for (int i = 0; i < LZP_WIN; i++) mem[i] = 0;
@@ -279,19 +301,43 @@ __device__ __forceinline__ void lz_parse_chunk(LzpLds& L, ChunkDesc* cd, const C
       for (int i = 0; i < LZP_WIN; i++) {
         unsigned long long m = 0;
         if (!ended && cur < 64u * (i + 1)) {
-          uint32_t c = cur - 64u * i, last = 0, h = 0;
-          while (c < 64) {
-            h = (uint32_t)__builtin_amdgcn_readlane((int)hop[i], (int)c);
-            m |= 1ull << c;
-            last = c;
-            c += h;  // (a stop flag is >= 2^31: it ends the loop by itself)
-          }
-          if (h & LZP_STOP) {
-            ended = true;
-            m &= ~(1ull << last);
+          const uint32_t ew = cur - 64u * i;
+          const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)top[i], (int)ew);
+          const uint32_t nr = (uint32_t)__builtin_amdgcn_readlane((int)cnt[i], (int)ew);
+          if (nr > (KIND == 2 ? 8u : 16u)) {
+            uint32_t J[5], D = (hop[i] & LZP_STOP) ? 0u : 1u;
+            uint32_t nx = (hop[i] & LZP_STOP) ? hop[i] : lane + hop[i];
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+              J[r] = nx;
+              const int idx = (int)((nx & 63u) << 2);
+              const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)nx);
+              const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)D);
+              const bool in = nx < 64u;
+              D += in ? c : 0u;
+              nx = in ? t : nx;
+            }
+            const uint32_t De = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)ew);
+            const uint32_t hops = De - D;
+            uint32_t y = ew;
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+              const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((y & 63u) << 2), (int)J[r]);
+              y = ((hops >> r) & 1u) && y < 64u ? t : y;
+            }
+            const bool on = nx == x && D <= De && lane >= ew && y == lane && !(hop[i] & LZP_STOP);
+            m = __ballot(on);
           } else {
-            cur = 64u * i + c;
+            uint32_t c = ew, h = 0;
+            while (c < 64) {
+              h = (uint32_t)__builtin_amdgcn_readlane((int)hop[i], (int)c);
+              if (h & LZP_STOP) break;
+              m |= 1ull << c;
+              c += h;
+            }
           }
+          if (x & LZP_STOP) ended = true;
+          else cur = 64u * i + x;
         }
         mem[i] = m;
       }
@@ -308,7 +354,7 @@ __device__ __forceinline__ void lz_parse_chunk(LzpLds& L, ChunkDesc* cd, const C
             recs[base + k] = make_uint2(ra[i], rb[i]);
           } else {
             recs[base + 2 * k] = make_uint2(ra[i], rb[i]);
-            if (rc[i]) recs[base + 2 * k + 1] = make_uint2(rc[i], rd[i]);
+            recs[base + 2 * k + 1] = make_uint2(rc[i], rd[i]);  // (zeros behind the last sequence: lz_exec reads pairs)
           }
         }
         base += (KIND == 2 ? 1u : 2u) * (uint32_t)__builtin_popcountll(m);
