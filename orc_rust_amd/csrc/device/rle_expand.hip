@@ -79,9 +79,12 @@ __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, uint32_t lane
   return v;
 }
 
+// ob == 4 under a 64-bit decoder (dictionary keys): values outside 0 ..= i32::MAX are stored as -1 -- no key of that size is
+// valid (DictionaryArray::try_new), and the consumer reports them like any other key out of bounds
+template <bool NARROW = false>
 __device__ __forceinline__ void store_val(void* out, uint32_t ob, uint64_t i, int64_t v) {
   if (ob == 8) ((int64_t*)out)[i] = v;
-  else if (ob == 4) ((int32_t*)out)[i] = (int32_t)v;
+  else if (ob == 4) ((int32_t*)out)[i] = NARROW && (v < 0 || v > 0x7fffffffll) ? -1 : (int32_t)v;
   else if (ob == 2) ((int16_t*)out)[i] = (int16_t)v;
   else ((int8_t*)out)[i] = (int8_t)v;
 }
@@ -143,7 +146,7 @@ __device__ __forceinline__ void direct_pair_load(const uint8_t* pp, uint32_t i0,
   }
 }
 
-template <int CODEC, int OB>
+template <int CODEC, int OB, int NB = OB * 8>
 __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, const uint64_t* scalars, uint32_t lg, WaveLds& L,
                                              uint32_t lane PROF_PARM) {
   const uint8_t* data = as_global(j->data);
@@ -151,7 +154,8 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
   const uint64_t len = scalars[j->len_idx];
   const uint64_t needed = scalars[j->needed_idx];
   const bool is_signed = j->is_signed;
-  constexpr int nbits = OB * 8;   // the reference's NInt width always equals the Arrow value width
+  constexpr int nbits = NB;       // the reference's NInt width: the Arrow value width, but for dictionary keys (64-bit decoder, 32-bit keys)
+  constexpr bool narrow = NB != OB * 8;
   constexpr uint32_t ob = OB;
   const uint32_t G = j->group_size;
   const uint32_t eof_code = CODEC == CODEC_BYTE ? ORC_E_IO : ORC_E_OUT_OF_SPEC;
@@ -266,7 +270,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             uint64_t oo = o0 + i0 + u * 64 + lane;
-            if (oo < needed) store_val(out, ob, oo, v[u]);
+            if (oo < needed) store_val<narrow>(out, ob, oo, v[u]);
           }
           if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[cur] - 1);
           q0 += 512;
@@ -345,7 +349,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             uint64_t oo = o0 + i0 + u * 64 + lane;
-            if (oo < needed) store_val(out, ob, oo, v[u]);
+            if (oo < needed) store_val<narrow>(out, ob, oo, v[u]);
           }
           if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[cur] - 1);
           q0 += 256;
@@ -370,7 +374,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           int64_t v = decode_b1(m & 0xff, (m >> 8) & 0xff, L.base[r], L.delta[r], data + L.pay[r], idx, is_signed, nbits, bad);
           if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[r] - 1);
           uint64_t oo = o0 + idx;
-          if (oo < needed) store_val(out, ob, oo, v);
+          if (oo < needed) store_val<narrow>(out, ob, oo, v);
         }
         q0 += 64;
       }
@@ -407,8 +411,8 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
         int64_t mag = db < 0 ? (int64_t)(0 - (uint64_t)db) : db;
         int64_t v1 = add ? (int64_t)((uint64_t)base + (uint64_t)mag) : (int64_t)((uint64_t)base - (uint64_t)mag);
         bad = (add ? add_ovf(base, mag, v1) : sub_ovf(base, mag, v1)) || !in_range_n(v1, nbits);
-        if (lane == 0 && o0 < needed) store_val(out, ob, o0, base);
-        if (lane == 1 && o0 + 1 < needed) store_val(out, ob, o0 + 1, v1);
+        if (lane == 0 && o0 < needed) store_val<narrow>(out, ob, o0, base);
+        if (lane == 1 && o0 + 1 < needed) store_val<narrow>(out, ob, o0 + 1, v1);
         // n - 2 <= 510 packed deltas: lane l owns deltas 8l .. 8l+7 (for 8-bit deltas that is one
         // 8-byte load), sums them locally, ONE wave scan over the lane totals gives every prefix,
         // and an LDS transpose turns the lane-major results into coalesced stores.
@@ -451,7 +455,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           uint32_t i = k * 64 + lane;
           if (i < nd) {
             uint64_t oo = o0 + 2 + i;
-            if (oo < needed) store_val(out, ob, oo, L.tile[i + (i >> 3)]);
+            if (oo < needed) store_val<narrow>(out, ob, oo, L.tile[i + (i >> 3)]);
           }
         }
         wave_sync();
@@ -497,7 +501,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
               int64_t v = (int64_t)((uint64_t)u + (uint64_t)base);
               bad |= add_ovf(u, base, v) || !in_range_n(v, nbits);  // checked_add in N
               uint64_t oo = o0 + i;
-              if (oo < needed) store_val(out, ob, oo, v);
+              if (oo < needed) store_val<narrow>(out, ob, oo, v);
             }
           }
         }
@@ -506,7 +510,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           int64_t pbits = trunc_n((int64_t)(patch << w), nbits);
           int64_t v = trunc_n((int64_t)((uint64_t)(u | pbits) + (uint64_t)base), nbits);  // wrapping_add in N
           uint64_t oo = o0 + ppos;
-          if (oo < needed) store_val(out, ob, oo, v);
+          if (oo < needed) store_val<narrow>(out, ob, oo, v);
         }
         wave_sync();
       } else if (CODEC == CODEC_RLE1 && type == RT_V1_LIT) {
@@ -527,7 +531,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
             varint_n(data + s, len - s, nbits, &u, &e);
             int64_t v = is_signed ? zigzag_n(u, nbits) : trunc_n((int64_t)u, nbits);
             uint64_t oo = o0 + rank;
-            if (oo < needed) store_val(out, ob, oo, v);
+            if (oo < needed) store_val<narrow>(out, ob, oo, v);
           }
           if (tm) vstart = c + (63 - __builtin_clzll(tm)) + 1;
           done += (uint32_t)__builtin_popcountll(tm);
@@ -561,7 +565,10 @@ __device__ __forceinline__ void expand_entry(RleJob* jobs, const uint32_t* group
     // wave-uniform dispatch on the value width: the bodies are specialised at compile time
     switch (j->out_bytes) {
       case 8: expand_group<CODEC, 8>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;
-      case 4: expand_group<CODEC, 4>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;
+      case 4:
+        if (j->nbits == 64) expand_group<CODEC, 4, 64>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
+        else expand_group<CODEC, 4>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
+        break;
       default: expand_group<CODEC, 2>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;
     }
   }

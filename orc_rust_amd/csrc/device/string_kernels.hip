@@ -118,13 +118,12 @@ extern "C" __global__ void __launch_bounds__(256) batch_base_kernel(const unsign
 // DictionaryStringArrayDecoder::next_batch (array_decoder/string.rs:204-224) per batch: keys
 // (bounds-checked) -> lengths -> int32 offsets restarting at 0 -> gather of the entries.
 struct DictJob {
-  const int64_t* dense;             // decoded keys of the non-null rows
+  const int32_t* dense;             // decoded keys of the non-null rows (-1: not a possible key, see store_val)
   const unsigned long long* vbits;  // stripe-wide validity words (null: no PRESENT stream)
   const uint32_t* rank;             // non-null rows before each 64-row word
   const int32_t* doff;              // dictionary offsets (dict_n + 1)
   const uint8_t* dbytes;            // dictionary bytes
   int32_t* offsets;                 // out: batch b at b * (batch + 1)
-  int32_t* keys;                    // workspace: key per row (0 for nulls)
   unsigned long long* chartot;      // per-batch byte totals, then (at + n_batches) their exclusive scan
   unsigned long long* err;
   const unsigned long long* dict_err;  // error word of the dictionary itself (bad lengths / short blob): nothing of it may be touched then
@@ -143,7 +142,6 @@ __device__ __forceinline__ DictJob dict_job(const DictJob* jobs, uint32_t i) {
   j.doff = glob(j.doff);
   j.dbytes = glob(j.dbytes);
   j.offsets = glob(j.offsets);
-  j.keys = glob(j.keys);
   j.chartot = glob(j.chartot);
   j.err = glob(j.err);
   j.dict_err = glob(j.dict_err);
@@ -184,7 +182,7 @@ extern "C" __global__ void __launch_bounds__(256) dict_rows_kernel(const DictJob
     for (uint32_t k0 = tid; k0 < DICT_TILE; k0 += 256 * 8) {
       unsigned long long word[8];
       uint32_t rk[8];
-      int64_t v[8];
+      int32_t v[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const uint32_t k = k0 + u * 256;
@@ -208,18 +206,15 @@ extern "C" __global__ void __launch_bounds__(256) dict_rows_kernel(const DictJob
         const uint64_t i = row0 + t0 + k;
         const bool valid = k < tn && ((word[u] >> (i & 63)) & 1);
         uint32_t len = 0;
-        int32_t key = 0;
         if (valid) {
           if (!dict_ok) {
             // (the dictionary error is what the column reports)
           } else if (v[u] < 0 || (uint64_t)v[u] >= dict_n) {
             report_err64(j.err, i, ORC_E_ARROW);
           } else {
-            key = (int32_t)v[u];
             len = cached ? (uint32_t)(doffc[v[u] + 1] - doffc[v[u]]) : (uint32_t)(j.doff[v[u] + 1] - j.doff[v[u]]);
           }
         }
-        if (k < tn) j.keys[i] = key;
         lens[k + (k >> 5)] = len;
       }
     }
@@ -319,12 +314,23 @@ extern "C" __global__ void __launch_bounds__(256) dict_gather2_kernel(const Dict
     // four rows per trip: offsets and keys of all four are requested before any is used
     uint32_t o[4], e[4];
     int32_t key[4];
+    unsigned long long word[4];
+    uint32_t rk[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const uint32_t k = k0 + u * 256 < rows ? k0 + u * 256 : k0;
       o[u] = (uint32_t)off[k];
       e[u] = (uint32_t)off[k + 1];
-      key[u] = j.keys[row0 + k];
+      word[u] = j.vbits ? j.vbits[(row0 + k) >> 6] : ~0ull;
+      rk[u] = j.vbits ? j.rank[(row0 + k) >> 6] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      // the row's key: a row with bytes is a non-null row with a key inside the dictionary (dict_rows_kernel)
+      const uint32_t k = k0 + u * 256 < rows ? k0 + u * 256 : k0;
+      const uint64_t i = row0 + k;
+      const uint64_t di = j.vbits ? (uint64_t)rk[u] + __builtin_popcountll(word[u] & ((1ull << (i & 63)) - 1)) : i;
+      key[u] = e[u] != o[u] ? j.dense[di] : 0;
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {

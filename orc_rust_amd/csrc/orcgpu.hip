@@ -506,7 +506,7 @@ struct ColPlan {
   int job_present = -1, job_data = -1, job_length = -1, job_secondary = -1;
   bool is_dict = false;
   uint32_t dictn_idx = 0, dicttotal_idx = 0, dicterr_idx = 0, utf8err_idx = 0;
-  uint64_t dictlens_off = 0, keys_off = 0;
+  uint64_t dictlens_off = 0;
   uint64_t n_term_words = 0, tmask_off = 0, tpop_off = 0, trank_off = 0, ttiles_off = 0;
   uint64_t dense_off = 0, dense2_off = 0;  // dense temporaries in scratch
   // strings
