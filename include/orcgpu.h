@@ -259,8 +259,10 @@ int orcgpu_last_timing(const orcgpu_ctx* ctx, float* total_ms, float* expand_ms,
  *   0 block decompression (compression.rs:142-195)      1 run-boundary walk + output position scans
  *   2 PRESENT streams -> validity / ranks               3 RLE expansion (the three *_expand kernels)
  *   4 finishers (null spacing, strings, decimals, timestamps) + the summary copy
+ *   5 (part of 0) the first stage of the block decompressors alone: Zstandard entropy decoding / Snappy and LZ4 token parsing;
+ *     0 minus 5 = the LZ77 execution kernels (and DEFLATE, which is one kernel)
  * ms[0..n) receives the first n of them. */
-#define ORCGPU_N_PHASES 5
+#define ORCGPU_N_PHASES 6
 int orcgpu_last_phase_ms(const orcgpu_ctx* ctx, float* ms, uint32_t n);
 
 #ifdef __cplusplus

@@ -238,13 +238,13 @@ class Context:
         return a.value, b.value, c.value
 
 
-    PHASES = ("decompress", "walk", "present", "expand", "finish")
+    PHASES = ("decompress", "walk", "present", "expand", "finish")  # + "decompress_stage1": the part of "decompress" spent in its first stage
 
     def phase_ms(self):
         """Device milliseconds of the last decode call per pipeline phase (orcgpu_last_phase_ms)."""
-        a = (C.c_float * 5)()
-        self.L.orcgpu_last_phase_ms(self.h, a, 5)
-        return dict(zip(self.PHASES, [float(x) for x in a]))
+        a = (C.c_float * 6)()
+        self.L.orcgpu_last_phase_ms(self.h, a, 6)
+        return dict(zip(self.PHASES + ("decompress_stage1",), [float(x) for x in a]))
 
 
 class Staged:

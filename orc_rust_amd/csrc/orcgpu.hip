@@ -234,9 +234,9 @@ struct orcgpu_ctx {
   DevBuf scratch;
   uint8_t* pinned = nullptr;
   size_t pinned_cap = 0;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk
+  hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk, after the decompressors' first stage
   float last_total_ms = 0, last_expand_ms = 0;
-  float last_phase_ms[ORCGPU_N_PHASES] = {0, 0, 0, 0, 0};
+  float last_phase_ms[ORCGPU_N_PHASES] = {0, 0, 0, 0, 0, 0};
   uint32_t last_expand_launches = 0;
   // ---- staging pipeline (lane 0 only): a copy stream, two pinned pieces filled by a few host threads while the other one
   // is on its way to HBM, a pool of stripe arenas ----

@@ -43,6 +43,7 @@ def lib():
         L = C.CDLL(build())
         pp, ps = C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)
         L.orcgen_rle2.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, pp, ps, C.c_void_p]
+        L.orcgen_rle2_segments.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, pp, ps, C.c_void_p]
         L.orcgen_rle1.argtypes = [C.c_void_p, C.c_size_t, C.c_int, pp, ps]
         L.orcgen_byte_rle.argtypes = [C.c_void_p, C.c_size_t, pp, ps]
         L.orcgen_bool.argtypes = [C.c_void_p, C.c_size_t, pp, ps]
@@ -68,6 +69,17 @@ def rle2(values, signed=True, aligned=True, stats=False):
     out, n = C.c_void_p(), C.c_size_t()
     st = np.zeros(4, dtype=np.uint64)
     lib().orcgen_rle2(v.ctypes.data, v.size, int(signed), int(aligned), C.byref(out), C.byref(n), st.ctypes.data)
+    buf = _take(out, n)
+    return (buf, dict(zip(("short_repeat", "direct", "patched_base", "delta"), st.tolist()))) if stats else buf
+
+
+def rle2_segments(values, seg_lens, signed=True, aligned=False, stats=False):
+    """RLE v2 with the encoder flushed behind every segment of seg_lens[k] values (forced run boundaries)."""
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    sl = np.ascontiguousarray(seg_lens, dtype=np.uint32)
+    out, n = C.c_void_p(), C.c_size_t()
+    st = np.zeros(4, dtype=np.uint64)
+    lib().orcgen_rle2_segments(v.ctypes.data, v.size, sl.ctypes.data, sl.size, int(signed), int(aligned), C.byref(out), C.byref(n), st.ctypes.data)
     buf = _take(out, n)
     return (buf, dict(zip(("short_repeat", "direct", "patched_base", "delta"), st.tolist()))) if stats else buf
 

@@ -385,6 +385,30 @@ int orcgen_rle2(const int64_t* vals, size_t n, int is_signed, int aligned, uint8
   return 0;
 }
 
+/* Public: like orcgen_rle2, but the encoder is flushed behind every segment (seg_lens[k] values each): run boundaries where the
+ * caller wants them, e.g. run lengths a writer would not normally produce */
+int orcgen_rle2_segments(const int64_t* vals, size_t n, const uint32_t* seg_lens, size_t n_seg, int is_signed, int aligned, uint8_t** out,
+                         size_t* out_len, uint64_t* stats) {
+  obuf b = {0, 0, 0};
+  rle2* e = (rle2*)calloc(1, sizeof(rle2));
+  e->out = &b;
+  e->is_signed = is_signed;
+  e->aligned = aligned;
+  size_t i = 0;
+  for (size_t k = 0; k < n_seg && i < n; k++) {
+    for (uint32_t t = 0; t < seg_lens[k] && i < n; t++) rle2_put(e, vals[i++]);
+    rle2_flush(e);
+  }
+  for (; i < n; i++) rle2_put(e, vals[i]);
+  rle2_flush(e);
+  if (stats) memcpy(stats, e->stats, sizeof(e->stats));
+  free(e);
+  ob_reserve(&b, 64);
+  *out = b.p;
+  *out_len = b.len;
+  return 0;
+}
+
 /* RLE v1 (spec: runs of 3..130 with delta -128..127, literal groups up to 128) */
 int orcgen_rle1(const int64_t* vals, size_t n, int is_signed, uint8_t** out, size_t* out_len) {
   obuf b = {0, 0, 0};

@@ -19,7 +19,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import boolean, compress_stream, lib, rle2, splitmix64, varint64
+from . import rle2_segments, boolean, compress_stream, lib, rle2, splitmix64, varint64
 
 BOOLEAN, BYTE, SHORT, INT, LONG, FLOAT, DOUBLE, STRING, BINARY, TIMESTAMP = range(10)
 DECIMAL, DATE = 14, 15
@@ -216,6 +216,33 @@ def c2_stripe(n, stripe_no, kind, row0=0, base=0):
     else:
         vals = np.cumsum((splitmix64(2 + stripe_no, n) % np.uint64(255)).astype(np.int64) + 1) + base
     stream, stats = rle2(vals, signed=True, aligned=True, stats=True)
+    cols = [{"column_id": 1, "orc_type": LONG, "encoding": DIRECT_V2, "name": "v"}]
+    return n, cols, [(1, DATA, stream)], {1: {"values": vals.tobytes()}}, stats
+
+
+def c2_adversarial_stripe(n, stripe_no):
+    """Int64 column built to defeat the stride guesses of the run walk (rle_scan.hip): run lengths drawn from 200..511, the
+    width changing from run to run (unaligned widths 3..40 bits), every third run with outliers (PATCHED_BASE), every
+    fifth a varying-delta run."""
+    seg = (splitmix64(91 + stripe_no, n // 200 + 2) % np.uint64(312)).astype(np.uint32) + 200
+    ends = np.cumsum(seg, dtype=np.int64)
+    k = int(np.searchsorted(ends, n)) + 1
+    seg = seg[:k]
+    r = splitmix64(92 + stripe_no, n)
+    run_of = np.repeat(np.arange(k, dtype=np.int64), seg)[:n]
+    width = (splitmix64(93 + stripe_no, k) % np.uint64(38)).astype(np.int64) + 3
+    vals = (r & ((np.uint64(1) << width[run_of].astype(np.uint64)) - np.uint64(1))).astype(np.int64)
+    kind = run_of % 15
+    # outliers: 12 per run of the "patched" runs, 20 bits above the run's width
+    pos_in_run = np.arange(n, dtype=np.int64) - np.concatenate(([0], ends[:k - 1]))[run_of]
+    out_mask = (kind % 3 == 1) & (pos_in_run % 37 == 5)
+    vals[out_mask] |= np.int64(1) << (width[run_of[out_mask]] + 18)
+    # varying deltas: a random walk with small steps
+    dl = kind % 5 == 2
+    steps = (r % np.uint64(200)).astype(np.int64) - 100
+    walk = np.cumsum(np.where(dl, steps, 0))
+    vals = np.where(dl, walk + (np.int64(1) << 33), vals)
+    stream, stats = rle2_segments(vals, seg, signed=True, aligned=False, stats=True)
     cols = [{"column_id": 1, "orc_type": LONG, "encoding": DIRECT_V2, "name": "v"}]
     return n, cols, [(1, DATA, stream)], {1: {"values": vals.tobytes()}}, stats
 

@@ -76,3 +76,15 @@ def test_c3_dictionary_utf8_with_present(compression):
         W.check_result(res, cols, expect)
         G.assert_column_parity(res, 0, cols[0], streams, n, 8192, compression=compression, what=("C3", compression))
         res.free()
+
+
+def test_c2_adversarial_walk():
+    """Run lengths 200..511 with the width changing from run to run and PATCHED_BASE runs in between: no stride guess of the run
+    walk holds, the verify + repair kernels carry the stream (rle_scan.hip).  Decoded values = generated values = oracle."""
+    n, cols, streams, expect, stats = W.c2_adversarial_stripe(1_500_000, 3)
+    assert stats["patched_base"] > 500 and stats["direct"] > 2000
+    res = decode_all([(n, cols, streams, expect)], "none")[0]
+    assert res.status()[0] == 0, res.status()
+    W.check_result(res, cols, expect)
+    G.assert_column_parity(res, 0, cols[0], streams, n, 8192, what="c2-adv")
+    res.free()
