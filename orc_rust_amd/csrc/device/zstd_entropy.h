@@ -256,7 +256,7 @@ __device__ __forceinline__ int zuni(int v) { return __builtin_amdgcn_readfirstla
 // The backward bit stream q[0 .. qn) is read from its last set bit downwards.  It is held in registers: lane j of `cur`
 // has dword (top - 63 + j) counted from `base` (q rounded down to 4 bytes), `nxt` the segment 48 dwords further down.
 __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uint32_t qn_, uint32_t nseq_, int ll_log_, int of_log_, int ml_log_,
-                                              uint32_t* seq_out_, uint32_t* dump_, uint32_t lane) {
+                                              uint32_t* seq_out_, uint32_t* dump_, uint32_t* progress, uint32_t lane) {
   const uint8_t* q = q_;      // (pointers stay what as_global() made them: global address space, vector registers)
   const uint32_t qn = zuni(qn_), nseq = zuni(nseq_);
   const int ll_log = zuni(ll_log_), of_log = zuni(of_log_), ml_log = zuni(ml_log_);
@@ -328,10 +328,19 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
   uint32_t* const sb = L.s.seqbuf;
   const uint32_t slot0 = lane < 3 ? lane : 192u + lane;
   const uint32_t slot_step = lane < 3 ? 3u : 0u;
+  // The execution kernel runs beside this one and takes the sequences as they come (lz_exec.h): they are stored write-through
+  // (agent scope, nothing stays dirty in this XCD's L2) and the count of sequences that have LANDED is published one flush
+  // late -- by then the stores of the flush before have long been acknowledged, so the wait costs nothing.
+  uint32_t published = 0;
   auto flush = [&](uint32_t first, uint32_t count) {  // sequences [first, first + count) are in seqbuf
     wave_sync();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (first > published) {
+      if (lane == 0) __hip_atomic_store(progress, first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      published = first;
+    }
     uint32_t* o = seq_out + 3ull * first;
-    for (uint32_t k = lane; k < 3 * count; k += 64) o[k] = sb[k];
+    for (uint32_t k = lane; k < 3 * count; k += 64) __hip_atomic_store(&o[k], sb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wave_sync();
   };
   const uint32_t tbase = (uint32_t)(uintptr_t)tb;  // LDS byte address of this lane's table
@@ -456,8 +465,11 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
 // Two independent jobs per compressed block, each a workgroup of one wavefront: blockIdx.x < n_blocks decodes the
 // SEQUENCES of block blockIdx.x (the long serial chain: those workgroups come first), blockIdx.x >= n_blocks decodes the
 // LITERALS of block blockIdx.x - n_blocks.  status_out[job] = 0, or a diagnostic code (any nonzero value rejects the chunk).
+// Both are read by the execution kernel while this one runs: status words start as ZSTD_PENDING, progress[b] counts the sequences
+// of block b that are in memory.
+#define ZSTD_PENDING 0xffffffffu
 extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBlock* __restrict__ blocks, uint32_t n_blocks, uint32_t* dump_words,
-                                                                     uint32_t* __restrict__ status_out) {
+                                                                     uint32_t* status_out, uint32_t* progress) {
   __shared__ ZEntLds L;
   const uint32_t job = blockIdx.x;
   if (job >= 2 * n_blocks) return;
@@ -541,11 +553,13 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
     PROF_MARK(3);
     if (!st) {
       if (p > end) st = 20;
-      else st = zfse_sequences(L, src + p, end - p, B.nseq, ll_log, of_log, ml_log, seq_out, dump, lane);
+      else st = zfse_sequences(L, src + p, end - p, B.nseq, ll_log, of_log, ml_log, seq_out, dump, (uint32_t*)as_global((void*)(progress + b)), lane);
     }
     PROF_MARK(4);
     PROF_COUNT(4, B.nseq);
   }
   PROF_END_AT(112);
-  if (lane == 0) status_out[job] = (uint32_t)st;
+  // everything this job wrote must be in memory before its status says so (the literals went out as ordinary stores)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (lane == 0) __hip_atomic_store(&status_out[job], (uint32_t)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

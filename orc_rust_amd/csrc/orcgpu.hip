@@ -235,6 +235,9 @@ struct orcgpu_ctx {
   uint8_t* pinned = nullptr;
   size_t pinned_cap = 0;
   hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk, after the decompressors' first stage
+  uint32_t n_cus = 0;
+  hipStream_t aux_stream = nullptr;   // the Zstandard execution kernel runs here, beside the entropy kernel on `stream`
+  hipEvent_t aux_ev[2] = {nullptr, nullptr};
   float last_total_ms = 0, last_expand_ms = 0;
   float last_phase_ms[ORCGPU_N_PHASES] = {0, 0, 0, 0, 0, 0};
   uint32_t last_expand_launches = 0;
@@ -562,6 +565,17 @@ orcgpu_ctx* orcgpu_open(int device, const orcgpu_opts* opts) {
       delete c;
       return nullptr;
     }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = (uint32_t)prop.multiProcessorCount;
+  }
+  // (without these the Zstandard stages simply run one after the other)
+  if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) c->aux_stream = nullptr;
+  for (auto& e : c->aux_ev)
+    if (c->aux_stream && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      (void)hipStreamDestroy(c->aux_stream);
+      c->aux_stream = nullptr;
+    }
   if (opts && opts->workspace_bytes) c->scratch.ensure(opts->workspace_bytes);
   c->lanes[0] = c;
   return c;
@@ -589,6 +603,9 @@ void orcgpu_close(orcgpu_ctx* c) {
   if (c->pinned) (void)hipHostFree(c->pinned);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->aux_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
