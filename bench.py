@@ -9,7 +9,7 @@ stripe_size = 64 MiB for this table), seeded synthetic data (orc_rust_amd/gen/tp
 A "step" decodes every stripe once: compressed stream bytes are already resident in HBM (staged through the C ABI
 before the timed region), Arrow buffers are left in HBM.
 
-    python bench.py --gpus N --steps K --warmup W [--workload lineitem|c2|c2-direct|c2-delta|c2-arange|c2-adv|c3|c5]
+    python bench.py --gpus N --steps K --warmup W [--workload lineitem|c2|c2-direct|c2-delta|c2-arange|c2-adv|c2-rowgroup|c3|c5]
     (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
 Prints ONE JSON line (rank 0).  `value` = whole-job decoded GB/s (Arrow bytes out of all ranks / time of the slowest
@@ -87,12 +87,12 @@ def build_workload(args, rank, world):
         base = 0
         for s in range(n_stripes):
             n = min(C2_STRIPE_ROWS, rows - s * C2_STRIPE_ROWS)
-            kind = {"c2": "direct" if s % 2 == 0 else "delta", "c2-direct": "direct", "c2-delta": "delta", "c2-arange": "arange", "c2-adv": "adv"}[wl]
+            kind = {"c2": "direct" if s % 2 == 0 else "delta", "c2-direct": "direct", "c2-delta": "delta", "c2-arange": "arange", "c2-adv": "adv", "c2-rowgroup": "rg"}[wl]
             if s in mine:
-                stripes.append(W.c2_adversarial_stripe(n, s)[:4] if kind == "adv" else W.c2_stripe(n, s, kind, row0=s * C2_STRIPE_ROWS)[:4])
+                stripes.append(W.c2_adversarial_stripe(n, s)[:4] if kind == "adv" else (W.c2_rowgroup_stripe(n, s)[:4] if kind == "rg" else W.c2_stripe(n, s, kind, row0=s * C2_STRIPE_ROWS)[:4]))
         label = "C2%s: RLEv2 Int64 column, %d rows, uncompressed, %d stripes" % (
             " (DIRECT 48-bit / DELTA 8-bit alternating)" if wl == "c2" else (
-                " adversarial walk (run lengths 200..511, widths 3..58 bits changing per run, every third run PATCHED_BASE)" if wl == "c2-adv" else " variant " + wl[3:]),
+                " DIRECT 48-bit with the encoder flushed every 10 000 rows (row-group boundaries of a real writer)" if wl == "c2-rowgroup" else " adversarial walk (run lengths 200..511, widths 3..58 bits changing per run, every third run PATCHED_BASE)" if wl == "c2-adv" else " variant " + wl[3:]),
             rows, n_stripes)
     elif wl == "c3":
         comp = args.compression or "snappy"
@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lineitem", choices=["lineitem", "c2", "c2-direct", "c2-delta", "c2-arange", "c2-adv", "c3", "c5"],
+    ap.add_argument("--workload", default="lineitem", choices=["lineitem", "c2", "c2-direct", "c2-delta", "c2-arange", "c2-adv", "c2-rowgroup", "c3", "c5"],
                     help="lineitem (default) = the headline; the others are BASELINE.md's remaining configs, recorded under profiles/")
     ap.add_argument("--compression", default=None, choices=[None, "none", "zstd", "snappy", "lz4", "zlib"])
     ap.add_argument("--rows", type=int, default=0, help="0 = the config's own size")

@@ -25,6 +25,8 @@
 #include "rle_kernels.h"
 #include "rle_parse.h"
 
+#define RLE_MEND_MIN 64u  // inconsistent blocks a stream must have for the parallel mending passes (rle_mend_kernel)
+
 // Phase timing for development builds (-DORC_PROF): per-phase sum / max of wavefront wall-clock ticks (10 ns).
 #ifdef ORC_PROF
 __device__ unsigned long long g_prof[176];  // [0, 32): walk kernels, [32, 48): counters, [48, 80): decompressors, [80, 112): lz_exec, [112, 144): zstd_entropy, [144, 176): counters
@@ -512,7 +514,17 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
     }
     return;
   }
-  // mode 2: verify
+  // mode 2: verify; mode 5: verify again behind rle_mend_kernel (only the streams it worked on)
+  if (mode == 5) {
+    if (j->stat_bad < RLE_MEND_MIN) return;
+    // the bitmap words are written afresh (rle_mend_kernel reads them as a snapshot and leaves them alone)
+    const uint32_t want5 = lb == 0 ? 0u : blk.exit_[b - 1];
+    const bool bad = want5 != blk.entry[b];
+    const unsigned long long m = __ballot(bad);
+    blk.badmap[b >> 5] = (uint32_t)(lane < 32 ? m : m >> 32);  // (every lane of the half stores the same word)
+    if (bad) atomicMin(&j->first_bad, lb);
+    return;
+  }
   uint32_t want = lb == 0 ? 0u : blk.exit_[b - 1];
   if (want == blk.entry[b]) return;
   atomicMin(&j->first_bad, lb);
@@ -630,6 +642,9 @@ __device__ __forceinline__ void block_exit_table(const uint8_t* data, uint64_t l
 }
 
 #define RLE_SHORT_WAVES 8
+#ifndef RLE_SHORT_MIN_WEAK
+#define RLE_SHORT_MIN_WEAK 16  // unverified blocks (of 64) that make a span a short-run span; fewer: the relaxation rounds and rle_mend_kernel
+#endif
 // One span by a workgroup of RLE_SHORT_WAVES wavefronts: per round every wave builds the all-entries table of one block
 // (block_exit_table: the expensive, entry-independent part), then the chain takes one table lookup per block.
 template <int CODEC>
@@ -734,7 +749,7 @@ extern "C" __global__ void __launch_bounds__(64 * RLE_SHORT_WAVES) rle_walk_shor
   for (int s = 0; s < 8; s++) {
     const unsigned long long live_m = masks[s][0], weak_m = masks[s][1];
     // isolated weak blocks inside long-run streams are left to the relaxation rounds
-    if (__builtin_popcountll(weak_m) < 16) continue;
+    if (__builtin_popcountll(weak_m) < RLE_SHORT_MIN_WEAK) continue;
     uint32_t bw = bw8 + s * 64, lb0 = bw - j->block0;
     if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, tabs, curs, tid, live_m, weak_m PROF_ARG);
     else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, tabs, curs, tid, live_m, weak_m PROF_ARG);
@@ -876,6 +891,82 @@ __device__ __forceinline__ void repair_chain(RleJob* j, const RleBlocks& blk, ui
       long_streak = 0;
     }
   }
+}
+
+// Inconsistent blocks mark short damaged stretches.  The typical cause: a writer flushes its encoder at every row-group boundary
+// (10 000 rows), so every twentieth run of an otherwise regular stream is short, the stride of the run headers breaks there, and
+// the few blocks around the boundary are guessed wrong while everything between boundaries is found and verified.  The stretches
+// are mended all at once, one LANE each (rle_mend_kernel): from where the block before the stretch says the chain comes in, block
+// after block, until the positions agree with what is recorded, the stretch's strong end or another lane's stretch is reached, or
+// RLE_MEND_STEPS blocks have been walked.  No block is written by two lanes, so a block's entry, exit and value count always
+// belong together -- the verify rounds compare exits with entries and rely on that.  A stretch whose start was itself wrong shows
+// up in the verify round that follows (mode 5) and is taken again; what is left after the passes goes to the serial
+// rle_repair_kernel, which is exact whatever happened before.  Streams with only a few inconsistent blocks skip all this
+// (RLE_MEND_MIN): the serial kernel is quicker for them.
+#define RLE_MEND_STEPS 64
+#define RLE_MEND_NEAR 48u
+extern "C" __global__ void __launch_bounds__(256) rle_mend_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars, uint32_t total_blocks) {
+  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t bw = b - lane;
+  if (bw >= total_blocks) return;
+  RleJob* j = const_cast<RleJob*>(find_job_by_block(jobs, njobs, bw));
+  if (j->stat_bad < RLE_MEND_MIN) return;  // (the whole wavefront: block ranges of a job are tile aligned)
+  const uint32_t lb = b - j->block0;
+  const uint64_t len = scalars[j->len_idx];
+  if (lb >= j->nblocks || !((uint64_t)lb * RLE_BLK < len || lb == 0)) return;
+  const uint32_t b0 = j->block0;
+  auto flagged = [&](uint32_t pb) { return ((blk.badmap[(b0 + pb) >> 5] >> ((b0 + pb) & 31)) & 1u) != 0; };
+  // A damaged stretch shows as several inconsistent blocks: its first block, seams between pieces of wrong chains inside it, and
+  // at its end a STRONG block (a header the search verified: true, inconsistent only with the wrong block before it).  One lane
+  // mends a stretch: the inconsistent block whose nearest inconsistent neighbour to the left (within RLE_MEND_NEAR blocks) is
+  // strong, or that has none.
+  if (!flagged(lb)) return;
+  for (uint32_t k = 1; k <= RLE_MEND_NEAR && k <= lb; k++)
+    if (flagged(lb - k)) {
+      if (!blk.flags[b0 + lb - k]) return;  // part of the stretch that block belongs to
+      break;
+    }
+  const uint8_t* data = as_global(j->data);
+  uint32_t nb = (uint32_t)((len + RLE_BLK - 1) / RLE_BLK);
+  if (nb > j->nblocks) nb = j->nblocks;
+  uint64_t pos = (uint64_t)lb * RLE_BLK + (lb == 0 ? 0u : blk.exit_[b - 1]);
+  uint32_t fill_from = lb, done = 0, last_flag = lb;
+  // what to do at block pb: 0 go on (rewrite it), 1 stop before it (another lane's, or the stretch's strong end)
+  auto ends_here = [&](uint32_t pb) -> bool {
+    if (pb == lb || !flagged(pb)) return false;
+    if (blk.flags[b0 + pb] || pb - last_flag > RLE_MEND_NEAR) return true;
+    last_flag = pb;
+    return false;
+  };
+  for (uint32_t it = 0; it < RLE_MEND_STEPS; it++) {
+    uint32_t c = pos < len ? (uint32_t)(pos / RLE_BLK) : nb;
+    if (c > nb) c = nb;
+    bool met = false;
+    for (uint32_t pb = fill_from; pb < c; pb++) {  // blocks the run before reaches over
+      if (ends_here(pb)) {
+        met = true;
+        break;
+      }
+      const uint64_t e = pos - (uint64_t)pb * RLE_BLK;
+      blk.entry[b0 + pb] = (uint32_t)e;
+      blk.exit_[b0 + pb] = e >= RLE_BLK ? (uint32_t)(e - RLE_BLK) : 0u;
+      blk.nvals[b0 + pb] = 0;
+    }
+    if (met || c >= nb || ends_here(c)) break;
+    const uint32_t want = (uint32_t)(pos - (uint64_t)c * RLE_BLK);
+    if (c != lb && !flagged(c) && blk.entry[b0 + c] == want) break;  // back on a recorded chain
+    uint32_t ex, nv;
+    walk_dispatch(j, data, len, c, want, &ex, &nv);
+    blk.entry[b0 + c] = want;
+    blk.exit_[b0 + c] = ex;
+    blk.nvals[b0 + c] = nv;
+    pos = (uint64_t)(c + 1) * RLE_BLK + ex;
+    fill_from = c + 1;
+    done++;
+  }
+  atomicAdd(&j->stat_repaired, done);
+  if (lb == j->first_bad) j->first_bad = 0xffffffffu;  // the verify round behind this kernel finds the first one again (the first inconsistent block of a stream always heads a stretch)
 }
 
 extern "C" __global__ void __launch_bounds__(64) rle_repair_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars) {

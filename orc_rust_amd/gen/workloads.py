@@ -220,6 +220,16 @@ def c2_stripe(n, stripe_no, kind, row0=0, base=0):
     return n, cols, [(1, DATA, stream)], {1: {"values": vals.tobytes()}}, stats
 
 
+def c2_rowgroup_stripe(n, stripe_no, stride=10000):
+    """C2's DIRECT shape as a real writer lays it out with a row index: the RLE encoder is flushed at every row-group boundary
+    (`stride` rows), so every 20th run is short (10 000 = 19 x 512 + 272) and the run stride of the stream keeps breaking."""
+    vals = (splitmix64(1 + stripe_no, n) & np.uint64((1 << 40) - 1)).astype(np.int64)
+    seg = np.full(n // stride + 1, stride, dtype=np.uint32)
+    stream, stats = rle2_segments(vals, seg, signed=True, aligned=True, stats=True)
+    cols = [{"column_id": 1, "orc_type": LONG, "encoding": DIRECT_V2, "name": "v"}]
+    return n, cols, [(1, DATA, stream)], {1: {"values": vals.tobytes()}}, stats
+
+
 def c2_adversarial_stripe(n, stripe_no):
     """Int64 column built to defeat the stride guesses of the run walk (rle_scan.hip): run lengths drawn from 200..511, the
     width changing from run to run (unaligned widths 3..40 bits), every third run with outliers (PATCHED_BASE), every

@@ -88,3 +88,15 @@ def test_c2_adversarial_walk():
     W.check_result(res, cols, expect)
     G.assert_column_parity(res, 0, cols[0], streams, n, 8192, what="c2-adv")
     res.free()
+
+
+def test_c2_rowgroup_flushes():
+    """DIRECT runs with the encoder flushed every 10 000 rows (what a writer with a row index produces): the run stride breaks at
+    every row-group boundary; the damaged stretches are mended in parallel (rle_mend_kernel), the result is exact."""
+    n, cols, streams, expect, stats = W.c2_rowgroup_stripe(2_000_000, 1)
+    assert stats["direct"] == 200 * 20
+    res = decode_all([(n, cols, streams, expect)], "none")[0]
+    assert res.status()[0] == 0, res.status()
+    W.check_result(res, cols, expect)
+    G.assert_column_parity(res, 0, cols[0], streams, n, 8192, what="c2-rowgroup")
+    res.free()
