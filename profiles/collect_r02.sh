@@ -20,6 +20,7 @@ run() {  # tag, bench args...
 for c in zstd snappy lz4 zlib none; do run lineitem_$c --workload lineitem --compression $c; done
 run c2 --workload c2
 run c2_adv --workload c2-adv --rows 24000000
+run c2_rowgroup --workload c2-rowgroup
 for c in none snappy zstd lz4 zlib; do run c3_$c --workload c3 --compression $c; done
 run c5_lz4 --workload c5 --compression lz4
 # 3. HBM traffic of the headline and of C3 / C2: FETCH_SIZE and WRITE_SIZE in passes of their own (no trace domains beside --kernel-trace)
