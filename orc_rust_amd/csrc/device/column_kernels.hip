@@ -122,7 +122,7 @@ extern "C" __global__ void __launch_bounds__(256) pres_scan_apply_kernel(const P
 }
 
 // Generic 2-level exclusive scan of u32 counts (tile = 1024 entries / workgroup).
-extern "C" __global__ void __launch_bounds__(256) scan_tiles_kernel(const uint32_t* in, uint32_t* out, uint32_t* tile_sum, uint64_t n) {
+__device__ __forceinline__ void scan_tiles_body(const uint32_t* in, uint32_t* out, uint32_t* tile_sum, uint64_t n) {
   __shared__ uint32_t wsum[4];
   uint64_t base = (uint64_t)blockIdx.x * 1024 + threadIdx.x * 4;
   uint32_t v[4];
@@ -145,7 +145,7 @@ extern "C" __global__ void __launch_bounds__(256) scan_tiles_kernel(const uint32
   if (threadIdx.x == 255) tile_sum[blockIdx.x] = e;
 }
 // single workgroup: exclusive scan of tile sums in place; total -> *total_out (u64)
-extern "C" __global__ void __launch_bounds__(256) scan_sums_kernel(uint32_t* tile_sum, uint64_t ntiles, uint64_t* total_out) {
+__device__ __forceinline__ void scan_sums_body(uint32_t* tile_sum, uint64_t ntiles, uint64_t* total_out) {
   __shared__ uint64_t wsum[4];
   __shared__ uint64_t carry_s;
   if (threadIdx.x == 0) carry_s = 0;
@@ -169,7 +169,7 @@ extern "C" __global__ void __launch_bounds__(256) scan_sums_kernel(uint32_t* til
   }
   if (threadIdx.x == 0 && total_out) *total_out = carry_s;
 }
-extern "C" __global__ void __launch_bounds__(256) scan_apply_kernel(uint32_t* out, const uint32_t* tile_sum, uint64_t n) {
+__device__ __forceinline__ void scan_apply_body(uint32_t* out, const uint32_t* tile_sum, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] += tile_sum[i >> 10];
 }
@@ -240,7 +240,7 @@ extern "C" __global__ void __launch_bounds__(256) space_multi_kernel(const Space
 }
 
 // Float/Double without nulls: plain copy of the raw little-endian stream (float.rs:70-74).
-extern "C" __global__ void __launch_bounds__(256) copy_bytes_kernel(const uint8_t* src, uint8_t* dst, uint64_t n) {
+__device__ __forceinline__ void copy_bytes_body(const uint8_t* src, uint8_t* dst, uint64_t n) {
   uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
   if (i + 16 <= n) {
     uint4 v;
@@ -254,7 +254,7 @@ extern "C" __global__ void __launch_bounds__(256) copy_bytes_kernel(const uint8_
 // Boolean DATA: dense MSB-first bit bytes -> per-batch LSB-first value bitmaps (BooleanArrayDecoder,
 // array_decoder/mod.rs:163-183).  One thread per output word; with nulls the dense bits are
 // deposited into the valid positions.
-extern "C" __global__ void __launch_bounds__(256) bool_values_kernel(const uint8_t* dbytes, const unsigned long long* vbits, const uint32_t* rank,
+__device__ __forceinline__ void bool_values_body(const uint8_t* dbytes, const unsigned long long* vbits, const uint32_t* rank,
                                                                       uint64_t n_rows, uint32_t batch, uint32_t words_per_batch,
                                                                       unsigned long long* out, uint64_t n_out_words) {
   uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -285,7 +285,7 @@ extern "C" __global__ void __launch_bounds__(256) bool_values_kernel(const uint8
 
 // Timestamp combine (encoding/timestamp.rs:121-192) fused with null spacing.
 // unit: 0 s, 1 ms, 2 us, 3 ns.
-extern "C" __global__ void __launch_bounds__(256) timestamp_kernel(const int64_t* secs, const int64_t* nanos, const unsigned long long* vbits,
+__device__ __forceinline__ void timestamp_body(const int64_t* secs, const int64_t* nanos, const unsigned long long* vbits,
                                                                     const uint32_t* rank, int64_t* out, uint64_t n_rows, int64_t base,
                                                                     int unit, unsigned long long* err) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -339,7 +339,7 @@ extern "C" __global__ void __launch_bounds__(256) timestamp_kernel(const int64_t
 }
 
 // Float/Double: read_exact of `needed` values must fit in the stream (float.rs:70-74 -> IoError).
-extern "C" __global__ void float_check_kernel(const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx, uint32_t width, uint64_t* err) {
+__device__ __forceinline__ void float_check_body(const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx, uint32_t width, uint64_t* err) {
   if (threadIdx.x == 0) {
     uint64_t have = scalars[len_idx] / width;
     if (have < scalars[needed_idx]) atomicMin((unsigned long long*)err, ((unsigned long long)have << 8) | ORC_E_IO);
@@ -418,7 +418,7 @@ extern "C" __global__ void __launch_bounds__(256) tz_shift_kernel(TzJob j) {
 }
 
 // all-ones validity words for a column without PRESENT whose values may still turn into nulls (tz_shift_kernel)
-extern "C" __global__ void __launch_bounds__(256) validity_ones_kernel(unsigned long long* validity, uint64_t n_rows, uint32_t batch, uint32_t words_per_batch,
+__device__ __forceinline__ void validity_ones_body(unsigned long long* validity, uint64_t n_rows, uint32_t batch, uint32_t words_per_batch,
                                                                         uint64_t n_words) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_words) return;

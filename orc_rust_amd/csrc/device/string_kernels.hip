@@ -18,7 +18,7 @@ __device__ __forceinline__ void report_err64(unsigned long long* err, uint64_t i
 // batch's lengths as they are (i64, negative ones included) and raises OffsetOverflow when the sum exceeds
 // i32::MAX; only then do negative lengths surface as an Arrow error.  A length outside 0..=i32::MAX is stored as 0
 // and added to the batch's correction term `corr[b]`, so that batch_offsets_kernel sees the exact signed sum.
-extern "C" __global__ void __launch_bounds__(256) string_lens_kernel(const int64_t* dense, const unsigned long long* vbits, const uint32_t* rank,
+__device__ __forceinline__ void string_lens_body(const int64_t* dense, const unsigned long long* vbits, const uint32_t* rank,
                                                                       int32_t* lens, uint64_t n_rows, uint32_t batch, unsigned long long* corr,
                                                                       unsigned long long* err) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -49,7 +49,7 @@ extern "C" __global__ void __launch_bounds__(256) string_lens_kernel(const int64
 // ---- per-batch exclusive scan of the lengths -> offsets (restart at 0 per batch) -------------------
 // One workgroup per batch.  offsets layout: batch b at b * (batch + 1).
 // corr: per-batch sum of the lengths string_lens_kernel stored as 0 (see there).
-extern "C" __global__ void __launch_bounds__(256) batch_offsets_kernel(const int32_t* lens, uint64_t n_rows, uint32_t batch, int32_t* offsets,
+__device__ __forceinline__ void batch_offsets_body(const int32_t* lens, uint64_t n_rows, uint32_t batch, int32_t* offsets,
                                                                         unsigned long long* chartot, const unsigned long long* corr,
                                                                         unsigned long long* err, uint32_t ovf_code) {
   __shared__ uint64_t wsum[4];
@@ -88,7 +88,7 @@ extern "C" __global__ void __launch_bounds__(256) batch_offsets_kernel(const int
 }
 
 // exclusive scan of the per-batch totals (single workgroup) -> charbase[b]; grand total -> *total
-extern "C" __global__ void __launch_bounds__(256) batch_base_kernel(const unsigned long long* chartot, unsigned long long* charbase, uint32_t n_batches,
+__device__ __forceinline__ void batch_base_body(const unsigned long long* chartot, unsigned long long* charbase, uint32_t n_batches,
                                                                      uint64_t* total) {
   __shared__ uint64_t wsum[4];
   __shared__ uint64_t carry_s;
@@ -371,7 +371,7 @@ extern "C" __global__ void __launch_bounds__(256) dict_gather2_kernel(const Dict
 }
 
 // ---- dictionary lengths -> dictionary offsets (single workgroup; the dictionary is loaded once per stripe)
-extern "C" __global__ void __launch_bounds__(256) dict_offsets_kernel(const int64_t* dlens, const uint64_t* scalars, uint32_t dict_n_idx,
+__device__ __forceinline__ void dict_offsets_body(const int64_t* dlens, const uint64_t* scalars, uint32_t dict_n_idx,
                                                                        uint32_t data_len_idx, int32_t* dict_off, uint64_t* dict_bytes_out,
                                                                        unsigned long long* err) {
   __shared__ uint64_t wsum[4];
@@ -428,7 +428,7 @@ __device__ __forceinline__ int utf8_lead_len(uint8_t c) {
   if (c >= 0xf0 && c <= 0xf4) return 4;
   return 0;  // continuation (0x80..0xbf) or invalid (0xc0, 0xc1, 0xf5..0xff)
 }
-extern "C" __global__ void __launch_bounds__(256) utf8_validate_kernel(const uint8_t* s, const uint64_t* scalars, uint32_t n_idx, uint32_t len_idx,
+__device__ __forceinline__ void utf8_validate_body(const uint8_t* s, const uint64_t* scalars, uint32_t n_idx, uint32_t len_idx,
                                                                         unsigned long long* err) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t n = scalars[n_idx];
@@ -473,7 +473,7 @@ extern "C" __global__ void __launch_bounds__(256) utf8_validate_kernel(const uin
 // charbase / chartot: per-batch byte base and size (nullptr for the dictionary: one "batch" of n_rows offsets).
 // Only bytes that exist are looked at (len_idx: the stream's real length); a batch that runs past them is reported
 // by string_data_check_kernel / dict_offsets_kernel.
-extern "C" __global__ void __launch_bounds__(256) utf8_boundaries_kernel(const uint8_t* s, const int32_t* offsets, const unsigned long long* charbase,
+__device__ __forceinline__ void utf8_boundaries_body(const uint8_t* s, const int32_t* offsets, const unsigned long long* charbase,
                                                                           const unsigned long long* chartot, uint64_t n_rows, uint32_t batch,
                                                                           const uint64_t* scalars, uint32_t n_idx, uint32_t len_idx,
                                                                           unsigned long long* err) {
@@ -501,7 +501,7 @@ extern "C" __global__ void __launch_bounds__(256) utf8_boundaries_kernel(const u
 }
 
 // Direct strings: the bytes consumed by all batches must exist in DATA (try_new: offsets past the buffer)
-extern "C" __global__ void string_data_check_kernel(const unsigned long long* chartot, const unsigned long long* charbase, uint32_t n_batches,
+__device__ __forceinline__ void string_data_check_body(const unsigned long long* chartot, const unsigned long long* charbase, uint32_t n_batches,
                                                     const uint64_t* scalars, uint32_t data_len_idx, uint32_t batch, unsigned long long* err) {
   uint32_t b = blockIdx.x * 64 + threadIdx.x;
   if (b >= n_batches) return;
@@ -510,7 +510,7 @@ extern "C" __global__ void string_data_check_kernel(const unsigned long long* ch
 
 // ---- Decimal: zigzag varints -> i128 ----------------------------------------------------------------
 // pass 1: per 64-byte word a bitmask of terminator bytes (top bit clear) + popcount
-extern "C" __global__ void __launch_bounds__(256) varint_terms_kernel(const uint8_t* s, const uint64_t* scalars, uint32_t len_idx, uint64_t n_words,
+__device__ __forceinline__ void varint_terms_body(const uint8_t* s, const uint64_t* scalars, uint32_t len_idx, uint64_t n_words,
                                                                        unsigned long long* tmask, uint32_t* tpop) {
   uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (w >= n_words) return;
@@ -532,7 +532,7 @@ extern "C" __global__ void __launch_bounds__(256) varint_terms_kernel(const uint
 }
 
 // pass 2: one thread per stream byte; terminators decode their varint into dense[k]
-extern "C" __global__ void __launch_bounds__(256) varint_decode128_kernel(const uint8_t* s, const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx,
+__device__ __forceinline__ void varint_decode128_body(const uint8_t* s, const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx,
                                                                            const unsigned long long* tmask, const uint32_t* trank, __int128* dense,
                                                                            uint64_t n_upper, unsigned long long* err) {
   uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -572,12 +572,12 @@ extern "C" __global__ void __launch_bounds__(256) varint_decode128_kernel(const 
   if (p == len - 1 && k + 1 < needed) report_err64(err, k + 1, ORC_E_IO);
 }
 // empty DATA stream with values needed
-extern "C" __global__ void varint_empty_check_kernel(const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx, unsigned long long* err) {
+__device__ __forceinline__ void varint_empty_check_body(const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx, unsigned long long* err) {
   if (threadIdx.x == 0 && scalars[len_idx] == 0 && scalars[needed_idx] > 0) report_err64(err, 0, ORC_E_IO);
 }
 
 // Decimal finish: null spacing + per-value scale repair (array_decoder/decimal.rs:138-166; release-build wrapping)
-extern "C" __global__ void __launch_bounds__(256) decimal_finish_kernel(const __int128* dense, const int32_t* scales, const unsigned long long* vbits,
+__device__ __forceinline__ void decimal_finish_body(const __int128* dense, const int32_t* scales, const unsigned long long* vbits,
                                                                          const uint32_t* rank, __int128* out, uint64_t n_rows, uint32_t fixed_scale) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_rows) return;

@@ -33,6 +33,7 @@
 #include "device/rle_parse.h"
 #include "device/rle_scan.hip"
 #include "device/rle_expand.hip"
+#include "device/multi_job.h"
 #include "device/column_kernels.hip"
 #include "device/string_kernels.hip"
 #include "device/decompress_kernels.hip"
@@ -234,6 +235,8 @@ struct orcgpu_ctx {
   DevBuf scratch;
   uint8_t* pinned = nullptr;
   size_t pinned_cap = 0;
+  uint8_t* fin_pinned = nullptr;       // staging of the finishers' job table
+  size_t fin_pinned_cap = 0;
   hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk, after the decompressors' first stage
   uint32_t n_cus = 0;
   hipStream_t aux_stream = nullptr;   // the Zstandard execution kernel runs here, beside the entropy kernel on `stream`
@@ -533,6 +536,8 @@ struct Plan {
   uint64_t dictjobs_off = 0;           // device copy of the DictJob table (scratch offset)
   uint64_t presjobs_off = 0;           // device copy of the PresJob table
   std::vector<PresJob> presjobs;
+  uint64_t finjobs_off = 0;            // device copy of the finishers' job table (FinBatch)
+  uint64_t finjobs_cap = 0;
   uint64_t spacejobs_off = 0;          // device copy of the SpaceJob table
   std::vector<SpaceJob> spacejobs;
   std::vector<DictJob> dictjobs;       // host copy, same order as pending_gathers
@@ -601,6 +606,7 @@ void orcgpu_close(orcgpu_ctx* c) {
     if (z.second->dev) (void)hipFree(z.second->dev);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->fin_pinned) (void)hipHostFree(c->fin_pinned);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : c->aux_ev)
@@ -862,6 +868,48 @@ hipError_t launch(void (*kernel)(Args...), uint64_t nthreads_or_blocks, bool is_
   hipLaunchKernelGGL(kernel, dim3((uint32_t)grid), dim3(bs), 0, st, args...);
   return hipGetLastError();
 }
+
+// The finishers' small launches, filed per (pipeline stage, kernel) and sent as one grid each (device/multi_job.h).
+struct FinBatch {
+  struct Entry {
+    int stage;
+    void (*launcher)(const MJob*, uint32_t, uint32_t, hipStream_t);
+    std::vector<MJob> jobs;
+    uint32_t max_blocks = 0;
+  };
+  std::vector<Entry> entries;
+  size_t n_jobs = 0;
+  template <auto Body, int BS>
+  static void launcher(const MJob* d, uint32_t n, uint32_t max_blocks, hipStream_t st) {
+    for (uint32_t o = 0; o < n; o += 65535u)
+      hipLaunchKernelGGL((mj_kernel<Body, BS>), dim3(max_blocks, std::min<uint32_t>(65535u, n - o)), dim3(BS), 0, st, d + o);
+  }
+  // same arguments as launch(): a thread (or block) count, then the kernel's own arguments
+  template <auto Body, int BS, typename... B>
+  void add(int stage, uint64_t nthreads_or_blocks, bool is_blocks, B... args) {
+    const uint64_t grid = is_blocks ? nthreads_or_blocks : (nthreads_or_blocks + BS - 1) / BS;
+    if (!grid) return;
+    auto fn = &launcher<Body, BS>;
+    Entry* e = nullptr;
+    for (auto& x : entries)
+      if (x.stage == stage && x.launcher == fn) e = &x;
+    if (!e) {
+      entries.push_back(Entry{stage, fn, {}, 0});
+      e = &entries.back();
+    }
+    MJob j{};
+    using S = MjSig<decltype(Body)>;
+    S::pack(j, std::make_index_sequence<S::n>{}, args...);
+    j.nblocks = (uint32_t)grid;
+    e->jobs.push_back(j);
+    e->max_blocks = std::max(e->max_blocks, j.nblocks);
+    n_jobs++;
+  }
+  void clear() {
+    entries.clear();
+    n_jobs = 0;
+  }
+};
 
 struct SummaryLayout {
   uint64_t scalars_off = 0, jobs_off = 0, nullc_off = 0, chartot_off = 0, bytes = 0;
