@@ -188,3 +188,92 @@ def test_malformed_snappy_is_rejected_like_the_oracle(case):
     res = G.gpu_decode(64, [c], [(1, DATA, stream)], compression="snappy", block_size=4096)
     assert res.status()[0] != 0
     G.assert_column_parity(res, 0, c, [(1, DATA, stream)], 64, 8192, compression="snappy", block_size=4096, what=case)
+
+
+# ---- hand-made LZ4 blocks: long length extensions, tiny offsets, the forms of the block's end -------------------------
+def lz4_seq(lit, off=None, mlen=0):
+    """One LZ4 sequence: literals, then (off, mlen >= 4) unless it is the block's last one (off None)."""
+    ll = len(lit)
+    ml = 0 if off is None else mlen - 4
+    out = bytearray([(min(ll, 15) << 4) | min(ml, 15)])
+    if ll >= 15:
+        r = ll - 15
+        out += b"\xff" * (r // 255) + bytes([r % 255])
+    out += lit
+    if off is not None:
+        out += off.to_bytes(2, "little")
+        if ml >= 15:
+            r = ml - 15
+            out += b"\xff" * (r // 255) + bytes([r % 255])
+    return bytes(out)
+
+
+def build_lz4(seed, total):
+    rng = np.random.default_rng(seed)
+    plain, body = bytearray(), bytearray()
+    while len(plain) < total:
+        kind = int(rng.integers(0, 6))
+        ll = [0, 3, 14, 15, 270, 70000][kind] if rng.random() < 0.5 else int(rng.integers(0, 40))
+        lit = rng.integers(0, 256, ll, dtype=np.uint8).tobytes()
+        plain += lit
+        if not plain:
+            plain += b"x"
+            lit = b"x"
+        off = int(rng.choice([1, 2, 3, 7, 64, 1000, 65535]))
+        off = max(1, min(off, len(plain)))
+        mlen = int(rng.choice([4, 5, 18, 19, 20, 274, 600, 9000]))
+        body += lz4_seq(lit, off, mlen)
+        start = len(plain) - off
+        for k in range(mlen):
+            plain.append(plain[start + k])
+    tail = rng.integers(0, 256, int(rng.integers(0, 30)), dtype=np.uint8).tobytes()
+    pad = (-(len(plain) + len(tail))) % 8
+    tail += bytes(pad)
+    plain += tail
+    body += lz4_seq(tail)
+    return bytes(plain), bytes(body)
+
+
+def lz4_stream(block):
+    h = len(block) << 1
+    return np.frombuffer(bytes([h & 0xFF, (h >> 8) & 0xFF, (h >> 16) & 0xFF]) + block, dtype=np.uint8).copy()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_handmade_lz4_sequences(seed):
+    plain, block = build_lz4(seed, 200000)
+    assert len(block) < len(plain) and len(block) < (1 << 23)
+    bs = 1 << 20
+    assert len(plain) <= bs
+    n = len(plain) // 8
+    c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+    stream = lz4_stream(block)
+    res = G.gpu_decode(n, [c], [(1, DATA, stream)], compression="lz4", block_size=bs)
+    assert res.status()[0] == 0, res.status()
+    got = b"".join(bytes(res.batch(b, 0)["values"]) for b in range(res.n_batches))
+    assert got == plain
+    G.assert_column_parity(res, 0, c, [(1, DATA, stream)], n, 8192, compression="lz4", block_size=bs, what=("lz4 handmade", seed))
+
+
+@pytest.mark.parametrize("case", ["offset0", "offset_too_far", "ends_with_match", "literal_overrun", "truncated_extension", "output_past_block", "empty"])
+def test_malformed_lz4_is_rejected_like_the_oracle(case):
+    data = bytes(range(64)) * 8
+    if case == "offset0":
+        block = lz4_seq(data[:40], 0, 8) + lz4_seq(data[:16])
+    elif case == "offset_too_far":
+        block = lz4_seq(data[:40], 41, 8) + lz4_seq(data[:16])
+    elif case == "ends_with_match":
+        block = lz4_seq(data[:40], 8, 24)
+    elif case == "literal_overrun":
+        block = bytes([0xF0, 200]) + data[:20]
+    elif case == "truncated_extension":
+        block = lz4_seq(data[:40], 8, 4) + bytes([0x4F]) + data[:4] + (8).to_bytes(2, "little") + b"\xff"  # match length extension cut off
+    elif case == "output_past_block":
+        block = lz4_seq(data[:40], 1, 9000) + lz4_seq(data[:8])
+    else:
+        block = b""
+    c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+    stream = lz4_stream(block) if block else np.array([0, 0, 0], dtype=np.uint8)
+    res = G.gpu_decode(64, [c], [(1, DATA, stream)], compression="lz4", block_size=4096)
+    assert res.status()[0] != 0
+    G.assert_column_parity(res, 0, c, [(1, DATA, stream)], 64, 8192, compression="lz4", block_size=4096, what=case)
