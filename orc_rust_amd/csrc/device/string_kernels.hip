@@ -149,7 +149,9 @@ __device__ __forceinline__ DictJob dict_job(const DictJob* jobs, uint32_t i) {
   j.total_out = glob(j.total_out);
   return j;
 }
+#ifndef DICT_TILE
 #define DICT_TILE 8192u
+#endif
 #define DICT_DOFF_LDS 2048u
 
 // One workgroup per (batch, column): keys -> lengths -> offsets.  Rows are read coalesced into an
@@ -285,7 +287,9 @@ extern "C" __global__ void __launch_bounds__(256) dict_base_kernel(const DictJob
 // One workgroup per (batch, column): the batch's value bytes are assembled in LDS (every thread
 // copies the entries of its rows to their offsets) and written to HBM as one coalesced run; batches
 // whose bytes do not fit go row by row straight to memory.
-#define DICT_CHARS_LDS 49152u
+#ifndef DICT_CHARS_LDS
+#define DICT_CHARS_LDS 16384u
+#endif
 #define DICT_BYTES_LDS 8192u
 extern "C" __global__ void __launch_bounds__(256) dict_gather2_kernel(const DictJob* jobs, const uint64_t* scalars) {
   __shared__ __attribute__((aligned(16))) uint8_t chars[DICT_CHARS_LDS + 16];
@@ -300,74 +304,132 @@ extern "C" __global__ void __launch_bounds__(256) dict_gather2_kernel(const Dict
   const uint32_t rows = (uint32_t)(j.n_rows - row0 < j.batch ? j.n_rows - row0 : j.batch);
   const int32_t* off = j.offsets + (uint64_t)b * ((uint64_t)j.batch + 1);
   uint8_t* out = j.out_chars + j.chartot[j.n_batches + b];
-  const bool staged = total <= DICT_CHARS_LDS;
   // small dictionaries are copied to LDS once per workgroup (offsets and bytes)
   const uint64_t dict_n = scalars[j.dict_n_idx];
   const uint32_t dict_bytes = dict_n <= DICT_DOFF_LDS ? (uint32_t)j.doff[dict_n] : 0xffffffffu;
-  const bool dcached = staged && dict_n <= DICT_DOFF_LDS && dict_bytes <= DICT_BYTES_LDS;
+  const bool dcached = dict_n <= DICT_DOFF_LDS && dict_bytes <= DICT_BYTES_LDS;
+  __shared__ uint32_t maxlen_s;
+  if (tid == 0) maxlen_s = 0;
+  __syncthreads();
   if (dcached) {
-    for (uint32_t i = tid; i <= dict_n; i += 256) doffc[i] = j.doff[i];
+    uint32_t ml = 0;
+    for (uint32_t i = tid; i <= dict_n; i += 256) {
+      const int32_t o = j.doff[i];
+      doffc[i] = o;
+      if (i < dict_n) {
+        const uint32_t l = (uint32_t)(j.doff[i + 1] - o);
+        ml = l > ml ? l : ml;
+      }
+    }
     for (uint32_t i = tid; i < dict_bytes; i += 256) dbc[i] = j.dbytes[i];
+    atomicMax(&maxlen_s, ml);
     __syncthreads();
   }
-  for (uint32_t k0 = tid; k0 < rows; k0 += 256 * 4) {
-    // four rows per trip: offsets and keys of all four are requested before any is used
-    uint32_t o[4], e[4];
-    int32_t key[4];
-    unsigned long long word[4];
-    uint32_t rk[4];
+  // The batch's bytes are assembled in LDS a TILE of rows at a time (as many rows as are certain to fit: the longest entry
+  // bounds a row) and written out as coalesced runs; a dictionary too big for LDS goes row by row straight to memory.
+  const uint32_t maxlen = maxlen_s;
+  const bool staged = dcached && maxlen > 0 && maxlen <= DICT_CHARS_LDS / 1024;  // (longer entries: few rows per tile, the direct path is quicker)
+  if (!staged) {
+    for (uint32_t k0 = tid; k0 < rows; k0 += 256 * 4) {
+      // four rows per trip: offsets, validity words and ranks of all four are requested before any is used, then the keys,
+      // then the dictionary offsets -- four chains of dependent loads side by side
+      uint32_t o[4], e[4], so[4];
+      int32_t key[4];
+      unsigned long long word[4];
+      uint32_t rk[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const uint32_t k = k0 + u * 256 < rows ? k0 + u * 256 : k0;
-      o[u] = (uint32_t)off[k];
-      e[u] = (uint32_t)off[k + 1];
-      word[u] = j.vbits ? j.vbits[(row0 + k) >> 6] : ~0ull;
-      rk[u] = j.vbits ? j.rank[(row0 + k) >> 6] : 0u;
-    }
+      for (int u = 0; u < 4; u++) {
+        const uint32_t k = k0 + u * 256 < rows ? k0 + u * 256 : k0;
+        o[u] = (uint32_t)off[k];
+        e[u] = (uint32_t)off[k + 1];
+        word[u] = j.vbits ? j.vbits[(row0 + k) >> 6] : ~0ull;
+        rk[u] = j.vbits ? j.rank[(row0 + k) >> 6] : 0u;
+      }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      // the row's key: a row with bytes is a non-null row with a key inside the dictionary (dict_rows_kernel)
-      const uint32_t k = k0 + u * 256 < rows ? k0 + u * 256 : k0;
-      const uint64_t i = row0 + k;
-      const uint64_t di = j.vbits ? (uint64_t)rk[u] + __builtin_popcountll(word[u] & ((1ull << (i & 63)) - 1)) : i;
-      key[u] = e[u] != o[u] ? j.dense[di] : 0;
-    }
+      for (int u = 0; u < 4; u++) {
+        const uint32_t k = k0 + u * 256 < rows ? k0 + u * 256 : k0;
+        const uint64_t i = row0 + k;
+        const uint64_t di = j.vbits ? (uint64_t)rk[u] + __builtin_popcountll(word[u] & ((1ull << (i & 63)) - 1)) : i;
+        key[u] = e[u] != o[u] ? j.dense[di] : 0;
+      }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (k0 + u * 256 >= rows) continue;
-      const uint32_t len = e[u] - o[u];
-      if (!len) continue;
-      uint8_t* d = staged ? chars + o[u] : out + o[u];
-      if (dcached) {
-        const uint8_t* src = dbc + doffc[key[u]];
-        for (uint32_t m = 0; m < len; m++) d[m] = src[m];
-      } else {
-        const uint8_t* src = j.dbytes + j.doff[key[u]];
-        uint32_t m = 0;
-        if (!staged)
+      for (int u = 0; u < 4; u++) so[u] = dcached ? (uint32_t)doffc[key[u]] : (uint32_t)j.doff[key[u]];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (k0 + u * 256 >= rows) continue;
+        const uint32_t len = e[u] - o[u];
+        if (!len) continue;
+        uint8_t* d = out + o[u];
+        if (dcached) {
+          const uint8_t* src = dbc + so[u];
+          for (uint32_t m = 0; m < len; m++) d[m] = src[m];
+        } else {
+          const uint8_t* src = j.dbytes + so[u];
+          uint32_t m = 0;
           for (; m + 8 <= len; m += 8) {
             uint64_t v = ld_u64(src + m);
             __builtin_memcpy(d + m, &v, 8);
           }
-        for (; m < len; m++) d[m] = src[m];
+          for (; m < len; m++) d[m] = src[m];
+        }
       }
     }
+    return;
   }
-  if (!staged) return;
-  __syncthreads();
-  // LDS -> HBM: bytes up to the first 16-byte boundary of the destination one by one, then 16 at a time
-  const uint32_t n = (uint32_t)total;
-  uint32_t head = (uint32_t)((16 - ((uintptr_t)out & 15)) & 15);
-  if (head > n) head = n;
-  if (tid < head) out[tid] = chars[tid];
-  const uint32_t body = (n - head) / 16;
-  for (uint32_t q = tid; q < body; q += 256) {
-    uint64_t v[2];
-    __builtin_memcpy(v, chars + head + q * 16, 16);
-    __builtin_memcpy(out + head + (uint64_t)q * 16, v, 16);
+  const uint32_t tile_rows = DICT_CHARS_LDS / maxlen;  // >= 1024
+  for (uint32_t r0 = 0; r0 < rows; r0 += tile_rows) {
+    const uint32_t r1 = r0 + tile_rows < rows ? r0 + tile_rows : rows;
+    const uint32_t base = (uint32_t)off[r0], n = (uint32_t)off[r1] - base;
+    if (n) {
+      for (uint32_t k0 = r0 + tid; k0 < r1; k0 += 256 * 4) {
+        // four rows per trip: offsets and keys of all four are requested before any is used
+        uint32_t o[4], e[4];
+        int32_t key[4];
+        unsigned long long word[4];
+        uint32_t rk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t k = k0 + u * 256 < r1 ? k0 + u * 256 : k0;
+          o[u] = (uint32_t)off[k];
+          e[u] = (uint32_t)off[k + 1];
+          word[u] = j.vbits ? j.vbits[(row0 + k) >> 6] : ~0ull;
+          rk[u] = j.vbits ? j.rank[(row0 + k) >> 6] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          // the row's key: a row with bytes is a non-null row with a key inside the dictionary (dict_rows_kernel)
+          const uint32_t k = k0 + u * 256 < r1 ? k0 + u * 256 : k0;
+          const uint64_t i = row0 + k;
+          const uint64_t di = j.vbits ? (uint64_t)rk[u] + __builtin_popcountll(word[u] & ((1ull << (i & 63)) - 1)) : i;
+          key[u] = e[u] != o[u] ? j.dense[di] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (k0 + u * 256 >= r1) continue;
+          const uint32_t len = e[u] - o[u];
+          if (!len) continue;
+          uint8_t* d = chars + (o[u] - base);
+          const uint8_t* src = dbc + doffc[key[u]];
+          for (uint32_t m = 0; m < len; m++) d[m] = src[m];
+        }
+      }
+      __syncthreads();
+      // LDS -> HBM: bytes up to the first 16-byte boundary of the destination one by one, then 16 at a time
+      uint8_t* o8 = out + base;
+      uint32_t head = (uint32_t)((16 - ((uintptr_t)o8 & 15)) & 15);
+      if (head > n) head = n;
+      if (tid < head) o8[tid] = chars[tid];
+      const uint32_t body = (n - head) / 16;
+      for (uint32_t q = tid; q < body; q += 256) {
+        uint64_t v[2];
+        __builtin_memcpy(v, chars + head + q * 16, 16);
+        __builtin_memcpy(o8 + head + (uint64_t)q * 16, v, 16);
+      }
+      const uint32_t done = head + body * 16;
+      if (tid < n - done) o8[done + tid] = chars[done + tid];
+      __syncthreads();
+    }
   }
-  const uint32_t done = head + body * 16;
-  if (tid < n - done) out[done + tid] = chars[done + tid];
 }
 
 // ---- dictionary lengths -> dictionary offsets (single workgroup; the dictionary is loaded once per stripe)
