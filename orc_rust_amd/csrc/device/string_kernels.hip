@@ -150,15 +150,16 @@ __device__ __forceinline__ DictJob dict_job(const DictJob* jobs, uint32_t i) {
   return j;
 }
 #ifndef DICT_TILE
-#define DICT_TILE 8192u
+#define DICT_TILE 4096u   // rows per tile (a batch takes several): 256 threads x DICT_PER consecutive rows each
 #endif
+#define DICT_PER (DICT_TILE / 256u)
 #define DICT_DOFF_LDS 2048u
 
 // One workgroup per (batch, column): keys -> lengths -> offsets.  Rows are read coalesced into an
 // LDS tile (padded: thread t then scans entries 32t..32t+31 without bank conflicts), one block scan
 // of the 256 partial sums, offsets written back coalesced.
 extern "C" __global__ void __launch_bounds__(256) dict_rows_kernel(const DictJob* jobs, const uint64_t* scalars) {
-  __shared__ uint32_t lens[DICT_TILE + DICT_TILE / 32];
+  __shared__ uint32_t lens[DICT_TILE + 256];
   __shared__ int32_t doffc[DICT_DOFF_LDS + 1];
   __shared__ uint64_t wsum[4];
   __shared__ uint64_t tbase[256];
@@ -217,15 +218,15 @@ extern "C" __global__ void __launch_bounds__(256) dict_rows_kernel(const DictJob
             len = cached ? (uint32_t)(doffc[v[u] + 1] - doffc[v[u]]) : (uint32_t)(j.doff[v[u] + 1] - j.doff[v[u]]);
           }
         }
-        lens[k + (k >> 5)] = len;
+        lens[k + k / DICT_PER] = len;
       }
     }
     __syncthreads();
-    // 2. thread-local exclusive scan of 32 consecutive entries
+    // 2. thread-local exclusive scan of DICT_PER consecutive entries
     uint64_t run = 0;
     {
-      const uint32_t base = tid * 33;
-      for (uint32_t m = 0; m < 32; m++) {
+      const uint32_t base = tid * (DICT_PER + 1);
+      for (uint32_t m = 0; m < DICT_PER; m++) {
         const uint32_t l = lens[base + m];
         lens[base + m] = (uint32_t)run;  // < 2^32: checked against i32::MAX per batch below
         run += l;
@@ -245,7 +246,7 @@ extern "C" __global__ void __launch_bounds__(256) dict_rows_kernel(const DictJob
     const uint64_t tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     __syncthreads();
     // 4. offsets, coalesced
-    for (uint32_t k = tid; k < tn; k += 256) out[t0 + k] = (int32_t)(tbase[k >> 5] + lens[k + (k >> 5)]);
+    for (uint32_t k = tid; k < tn; k += 256) out[t0 + k] = (int32_t)(tbase[k / DICT_PER] + lens[k + k / DICT_PER]);
     carry += tile_total;
     __syncthreads();
   }
