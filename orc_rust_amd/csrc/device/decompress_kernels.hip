@@ -212,9 +212,12 @@ __device__ __forceinline__ void lzin_literal(LzIn& in, LzOut& o, uint32_t pos, u
 #include "zstd_entropy.h"
 #include "lz_parse.h"
 #include "lz_exec.h"
+#include "inflate_parse.h"
 
 // DEFLATE chunks: one wavefront each ("original" chunks ride along when no other launch has taken them: copy_too).
-extern "C" __global__ void __launch_bounds__(64) decompress_deflate_kernel(ChunkDesc* chunks, uint32_t n_chunks, int copy_too) {
+// (`only_deferred`: the chunks inflate_parse_kernel / lz_exec_kernel left alone -- diag == LZX_DEFERRED; this decoder is the authority on
+// malformed streams)
+extern "C" __global__ void __launch_bounds__(64) decompress_deflate_kernel(ChunkDesc* chunks, uint32_t n_chunks, int copy_too, int only_deferred) {
   __shared__ DecompLds lds;
   __shared__ __attribute__((aligned(16))) LzStore<32768> lz;
   uint32_t c = blockIdx.x;
@@ -223,6 +226,7 @@ extern "C" __global__ void __launch_bounds__(64) decompress_deflate_kernel(Chunk
   PROF_BEGIN();
   ChunkDesc d = chunks[c];
   if (!(d.kind == 1 || (d.kind == 0 && copy_too))) return;
+  if (d.kind == 1 && only_deferred && d.diag != LZX_DEFERRED) return;
   d.src = as_global(d.src);  // plain global memory, not generic: see as_global()
   d.dst = (uint8_t*)as_global((void*)d.dst);
   uint32_t out_len = 0;

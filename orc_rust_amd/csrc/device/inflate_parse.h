@@ -1,0 +1,368 @@
+// inflate_parse.h -- token stage of the DEFLATE decompressor: ONE WAVEFRONT PER ORC CHUNK, its 64 lanes decoding
+// 64 stretches of the Huffman stream at once.
+//
+// Replaces the Huffman half of flate2's raw DeflateDecoder (compression.rs:142-149; RFC 1951).  A DEFLATE block is one
+// prefix-coded stream of tokens (literal | length + distance | end of block); where a token starts is known only by decoding
+// everything before it.  But prefix codes self-synchronise: a decoder started at a wrong bit falls in step with the true token
+// boundaries after a few tokens.  So the stream is taken a window at a time (64 segments of INF_SEG bits): every lane decodes
+// its segment from a guessed start up to the first token boundary behind the segment's end; then each lane compares its start
+// with the end its left neighbour reached and decodes again from there if they differ, until nothing moves (lane 0 starts at
+// the true position, so what comes out is exactly the serial decode); a counting pass and a writing pass follow.  Block headers
+// (code length tables) are decoded wave-uniformly by the code of inflate_device.h.
+//
+// Output per chunk: the literal bytes, back to back, and one {distance + 3, match length, literal length} record per match (the
+// format of zstd_entropy.h: lz_exec.h executes it).  Anything unexpected -- a malformed stream, a code the fast path does not
+// take -- leaves the chunk to the one-wavefront decoder (decompress_deflate_kernel), which is the authority on errors.
+#pragma once
+
+#define INF_SEG 256u                      // bits per lane and window
+#define INF_WIN_BYTES (64u * INF_SEG / 8u)  // 2 KiB
+#define INF_SLACK 16u                     // a token reads at most 48 bits past its first one; a lane stops within them
+
+struct InfLds {
+  HuffTab lit, dist;
+  uint8_t lens[320];
+  __attribute__((aligned(8))) uint8_t win[INF_WIN_BYTES + INF_SLACK + 16];
+  uint32_t end_pos[65];   // [i + 1]: where lane i's decode ended (bits from the window's first bit); [0]: the window's true start (0)
+  uint32_t n_lit[64], n_seq[64], tail_lit[64], carry_in[64];
+};
+
+struct InfTok {
+  uint32_t kind;   // 0 literal, 1 match, 2 end of block, 3 cannot be (the serial decoder decides what it is)
+  uint32_t bits;   // bits the token takes
+  uint32_t a, b;   // literal: byte; match: length, distance
+};
+
+// canonical decode of a code longer than the fast table's 10 bits (or an unused pattern): -1 = no such code
+__device__ __forceinline__ int inf_slow(uint64_t bits, const HuffTab& h, uint32_t& used) {
+  int code = 0, first = 0, index = 0;
+  for (int len = 1; len < 16; len++) {
+    code |= (int)(bits & 1);
+    bits >>= 1;
+    const int count = h.count[len];
+    if (code - count < first) {
+      used = (uint32_t)len;
+      return h.symbol[index + (code - first)];
+    }
+    index += count;
+    first += count;
+    first <<= 1;
+    code <<= 1;
+  }
+  return -1;
+}
+
+// the token at bit `pos` of the staged window (per lane: no cooperation)
+__device__ __forceinline__ InfTok inf_token(const uint8_t* win, uint32_t pos, const HuffTab& lc, const HuffTab& dc) {
+  uint64_t v;
+  __builtin_memcpy(&v, win + (pos >> 3), 8);
+  v >>= pos & 7;  // >= 57 bits
+  InfTok t{3, 0, 0, 0};
+  uint32_t used;
+  int sym;
+  uint32_t e = lc.fast[(uint32_t)v & 1023];
+  if (e) {
+    used = e >> 12;
+    sym = (int)(e & 0xfff);
+  } else {
+    sym = inf_slow(v, lc, used);
+    if (sym < 0) return t;
+  }
+  if (sym < 256) {
+    t.kind = 0;
+    t.bits = used;
+    t.a = (uint32_t)sym;
+    return t;
+  }
+  if (sym == 256) {
+    t.kind = 2;
+    t.bits = used;
+    return t;
+  }
+  sym -= 257;
+  if (sym >= 29) return t;
+  const uint32_t le = LEXT[sym];
+  const uint32_t len = LBASE[sym] + ((uint32_t)(v >> used) & ((1u << le) - 1));
+  used += le;
+  uint32_t du;
+  int ds;
+  e = dc.fast[(uint32_t)(v >> used) & 1023];
+  if (e) {
+    du = e >> 12;
+    ds = (int)(e & 0xfff);
+  } else {
+    ds = inf_slow(v >> used, dc, du);
+    if (ds < 0) return t;
+  }
+  if (ds >= 30) return t;
+  used += du;
+  const uint32_t de = DEXT[ds];
+  const uint32_t dist = DBASE[ds] + ((uint32_t)(v >> used) & ((1u << de) - 1));
+  used += de;
+  t.kind = 1;
+  t.bits = used;  // <= 15 + 5 + 15 + 13 = 48
+  t.a = len;
+  t.b = dist;
+  return t;
+}
+
+// One window of a Huffman block.  `bitpos`: the window's first bit (absolute, in the chunk); tokens are decoded while they START
+// before `limit` (bits from the window's start: the end of the input) .  Returns 0 = window done (bitpos advanced), 1 = end of
+// block met (bitpos behind it), 2 = leave the chunk to the serial decoder.  lit / seq: the chunk's output so far (uniform).
+__device__ __forceinline__ int inf_window(InfLds& L, const uint8_t* src, uint32_t n, uint64_t& bitpos, uint8_t* lit_out, uint32_t* seq_out, uint32_t& litn,
+                                          uint32_t& nseq, uint32_t& pending_ll, uint32_t lit_cap, uint32_t seq_cap, uint32_t lane) {
+  // ---- stage the window (byte aligned at its first bit's byte) ----
+  const uint32_t byte0 = (uint32_t)(bitpos >> 3), bit0 = (uint32_t)(bitpos & 7);
+  for (uint32_t k = lane * 8; k < INF_WIN_BYTES + INF_SLACK + 8; k += 512) {
+    uint64_t v = 0;
+    const uint64_t p = (uint64_t)byte0 + k;
+    if (p + 8 <= n) v = ld_u64(src + p);
+    else
+      for (uint32_t t = 0; t < 8; t++)
+        if (p + t < n) v |= (uint64_t)src[p + t] << (8 * t);
+    __builtin_memcpy(L.win + k, &v, 8);
+  }
+  const uint64_t total_bits = (uint64_t)n * 8;
+  const uint64_t left = total_bits - bitpos;  // bits of input from the window's first bit
+  const uint32_t seg_end = bit0 + (lane + 1) * INF_SEG;  // (positions are relative to the window's first BYTE)
+  wave_sync();
+  // decode from `start` while tokens begin before this lane's segment end; what = 0 count only, 1 write
+  uint32_t my_start = lane == 0 ? bit0 : bit0 + lane * INF_SEG;
+  uint32_t my_end = 0, my_flag = 0;  // flag: 1 end of block inside, 2 cannot decode
+  uint32_t c_lit = 0, c_seq = 0, c_tail = 0, c_first = 0;
+  auto run = [&](uint32_t start, bool write, uint32_t lit_base, uint32_t seq_base, uint32_t carry) {
+    uint32_t pos = start, flag = 0;
+    uint32_t nl = 0, ns = 0, run_ll = carry;
+    while (pos < seg_end) {
+      if ((uint64_t)pos - bit0 >= left) {
+        flag = 2;  // ran off the end of the input without an end of block
+        break;
+      }
+      const InfTok t = inf_token(L.win, pos, L.lit, L.dist);
+      if (t.kind == 3 || (uint64_t)pos - bit0 + t.bits > left) {
+        flag = 2;
+        break;
+      }
+      pos += t.bits;
+      if (t.kind == 2) {
+        flag = 1;
+        break;
+      }
+      if (t.kind == 0) {
+        if (write) lit_out[lit_base + nl] = (uint8_t)t.a;
+        nl++;
+        run_ll++;
+      } else {
+        if (write) {
+          uint32_t* q = seq_out + 3ull * (seq_base + ns);
+          q[0] = t.b + 3;  // an offset value above 3: a new offset (RFC 8878 3.1.1.5), as lz_exec reads it
+          q[1] = t.a;
+          q[2] = run_ll;
+        }
+        ns++;
+        run_ll = 0;
+      }
+    }
+    my_end = pos;
+    my_flag = flag;
+    c_lit = nl;
+    c_seq = ns;
+    c_tail = run_ll - (ns ? 0u : carry);  // literals behind the lane's last match (all of its own when it has none)
+    c_first = ns;
+  };
+  // ---- every lane from its guess, then again from where its left neighbour ended, until nothing moves ----
+  run(my_start, false, 0, 0, 0);
+  for (uint32_t round = 0; round < 64; round++) {
+    L.end_pos[lane + 1] = my_end;
+    if (lane == 0) L.end_pos[0] = bit0;
+    wave_sync();
+    const uint32_t want = L.end_pos[lane];
+    // a lane behind an end of block / a failure has nothing of its own: it passes the position on
+    const bool moved = want != my_start;
+    if (moved) {
+      my_start = want;
+      if (want >= seg_end) {
+        my_end = want;
+        my_flag = 0;
+        c_lit = c_seq = c_tail = 0;
+      } else {
+        run(want, false, 0, 0, 0);
+      }
+    }
+    wave_sync();
+    if (!__ballot(moved)) break;
+    if (round == 63) return 2;
+  }
+  // ---- the first lane (in stream order) that met the end of the block or could not decode ends the window ----
+  const unsigned long long stopm = __ballot(my_flag != 0);
+  uint32_t last_lane = 63;
+  int result = 0;
+  if (stopm) {
+    last_lane = (uint32_t)__builtin_ctzll(stopm);
+    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)my_flag, (int)last_lane);
+    if (f == 2) return 2;
+    result = 1;
+  }
+  const bool mine = lane <= last_lane;
+  // ---- positions: exclusive prefix sums of literals and matches; literals pending across lanes ----
+  const uint32_t nl = mine ? c_lit : 0, ns = mine ? c_seq : 0;
+  const uint32_t il = wave_incl_scan_u32(nl, lane), is = wave_incl_scan_u32(ns, lane);
+  const uint32_t tot_l = (uint32_t)__builtin_amdgcn_readlane((int)il, 63), tot_s = (uint32_t)__builtin_amdgcn_readlane((int)is, 63);
+  if ((uint64_t)litn + tot_l > lit_cap || (uint64_t)nseq + tot_s > seq_cap) return 2;
+  L.n_seq[lane] = ns;
+  L.tail_lit[lane] = mine ? c_tail : 0;
+  L.n_lit[lane] = nl;
+  wave_sync();
+  if (lane == 0) {
+    uint32_t carry = pending_ll;
+    for (uint32_t i = 0; i < 64; i++) {
+      L.carry_in[i] = carry;
+      carry = L.n_seq[i] ? L.tail_lit[i] : carry + L.n_lit[i];
+    }
+    L.end_pos[0] = carry;  // (reused: literals pending behind the window)
+  }
+  wave_sync();
+  const uint32_t carry = L.carry_in[lane];
+  const uint32_t new_pending = L.end_pos[0];
+  // ---- write ----
+  if (mine && (nl || ns)) run(my_start, true, litn + il - nl, nseq + is - ns, carry);
+  litn += tot_l;
+  nseq += tot_s;
+  pending_ll = new_pending;
+  const uint32_t end_rel = (uint32_t)__builtin_amdgcn_readlane((int)my_end, (int)last_lane);
+  bitpos = (uint64_t)byte0 * 8 + end_rel;
+  wave_sync();
+  return result;
+}
+
+// The chunk's blocks.  Returns 0 (litn, nseq final; trailing literals are the sequence-less rest) or 2 (serial decoder).
+__device__ __forceinline__ int inflate_parse_chunk(InfLds& L, LzLds Z, const uint8_t* src, uint32_t n, uint8_t* lit_out, uint32_t* seq_out, uint32_t lit_cap,
+                                                   uint32_t seq_cap, uint32_t& litn_out, uint32_t& nseq_out, uint32_t lane) {
+  LzIn in{src, n, Z.stage, 0};
+  lzin_stage(in, 0, lane);
+  BitRd b{src, n, 0, 0, 0, &in};
+  uint32_t litn = 0, nseq = 0, pending = 0;
+  uint32_t last;
+  do {
+    last = br_get(b, 1);
+    const uint32_t type = br_get(b, 2);
+    if (br_overrun(b)) return 2;
+    if (type == 0) {
+      const uint32_t drop = b.bc & 7;
+      b.bb >>= drop;
+      b.bc -= drop;
+      uint32_t bytepos = b.pos - (b.bc >> 3);
+      if (bytepos + 4 > n) return 2;
+      const uint32_t len = src[bytepos] | (src[bytepos + 1] << 8);
+      const uint32_t nlen = src[bytepos + 2] | (src[bytepos + 3] << 8);
+      bytepos += 4;
+      if ((len ^ 0xffffu) != nlen) return 2;
+      if (bytepos + len > n || (uint64_t)litn + len > lit_cap) return 2;
+      wave_copy(lit_out + litn, src + bytepos, len, lane);
+      litn += len;
+      pending += len;
+      b.pos = bytepos + len;
+      b.bb = 0;
+      b.bc = 0;
+      continue;
+    }
+    if (type == 1) {
+      for (uint32_t i = lane; i < 288; i += 64) L.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+      wave_sync();
+      huff_build_dev(L.lit, L.lens, 288, lane);
+      for (uint32_t i = lane; i < 30; i += 64) L.lens[i] = 5;
+      wave_sync();
+      huff_build_dev(L.dist, L.lens, 30, lane);
+    } else if (type == 2) {
+      const uint32_t nlen = br_get(b, 5) + 257, ndist = br_get(b, 5) + 1, ncode = br_get(b, 4) + 4;
+      if (br_overrun(b) || nlen > 286 || ndist > 30) return 2;
+      for (uint32_t i = lane; i < 19; i += 64) L.lens[i] = 0;
+      wave_sync();
+      for (uint32_t i = 0; i < ncode; i++) {
+        const uint32_t v = br_get(b, 3);
+        if (lane == 0) L.lens[CLORDER[i]] = (uint8_t)v;
+      }
+      wave_sync();
+      if (huff_build_dev(L.lit, L.lens, 19, lane) != 0) return 2;
+      uint32_t i = 0, prev = 0;
+      while (i < nlen + ndist) {
+        const int sym = huff_decode_dev(b, L.lit);
+        if (sym < 0) return 2;
+        if (sym < 16) {
+          if (lane == 0) L.lens[i] = (uint8_t)sym;
+          prev = (uint32_t)sym;
+          i++;
+        } else {
+          uint32_t len = 0, rep;
+          if (sym == 16) {
+            if (i == 0) return 2;
+            len = prev;
+            rep = 3 + br_get(b, 2);
+          } else if (sym == 17) {
+            rep = 3 + br_get(b, 3);
+          } else {
+            rep = 11 + br_get(b, 7);
+          }
+          if (i + rep > nlen + ndist) return 2;
+          for (uint32_t k = lane; k < rep; k += 64) L.lens[i + k] = (uint8_t)len;
+          prev = len;
+          i += rep;
+        }
+      }
+      if (br_overrun(b)) return 2;
+      wave_sync();
+      if (L.lens[256] == 0) return 2;
+      int r = huff_build_dev(L.dist, L.lens + nlen, (int)ndist, lane);
+      if (r < 0 || (r > 0 && (int)ndist - (int)L.dist.count[0] != 1)) return 2;
+      r = huff_build_dev(L.lit, L.lens, (int)nlen, lane);
+      if (r < 0 || (r > 0 && (int)nlen - (int)L.lit.count[0] != 1)) return 2;
+    } else {
+      return 2;
+    }
+    // ---- the block's tokens, a window at a time ----
+    uint64_t bitpos = (uint64_t)b.pos * 8 - b.bc;
+    for (;;) {
+      const int r = inf_window(L, src, n, bitpos, lit_out, seq_out, litn, nseq, pending, lit_cap, seq_cap, lane);
+      if (r == 2) return 2;
+      if (r == 1) break;
+    }
+    if (bitpos > (uint64_t)n * 8) return 2;
+    // the bit reader goes on behind the block
+    b.pos = (uint32_t)(bitpos >> 3);
+    b.bb = 0;
+    b.bc = 0;
+    if (bitpos & 7) {
+      if (b.pos >= n) return 2;
+      (void)br_get(b, (uint32_t)(bitpos & 7));  // (refills from b.pos: the bits of that byte below the position are dropped)
+    }
+  } while (!last);
+  litn_out = litn;
+  nseq_out = nseq;
+  return 0;
+}
+
+// ChunkDesc of a DEFLATE chunk: scratch = [literal bytes: dst_cap + 16][records: 12 x (dst_cap / 3 + 2)]; the kernel leaves
+// n_items = records, pad = literal bytes, diag = 0 -- or diag = LZX_DEFERRED: not decoded here, decompress_deflate_kernel takes it.
+extern "C" __global__ void __launch_bounds__(64) inflate_parse_kernel(ChunkDesc* chunks, uint32_t n_chunks) {
+  __shared__ InfLds L;
+  __shared__ __attribute__((aligned(16))) uint8_t stage[LZ_STAGE + 16];
+  const uint32_t c = blockIdx.x;
+  if (c >= n_chunks) return;
+  const ChunkDesc d = chunks[c];
+  if (d.kind != 1) return;
+  const uint32_t lane = threadIdx.x;
+  const uint8_t* src = as_global(d.src);
+  uint8_t* sc = (uint8_t*)as_global((void*)d.scratch);
+  const uint32_t lit_cap = d.dst_cap;
+  const uint32_t seq_cap = d.dst_cap / 3 + 2;
+  uint8_t* lit_out = sc;
+  uint32_t* seq_out = reinterpret_cast<uint32_t*>(sc + ((lit_cap + 16 + 15) & ~15u));
+  uint32_t litn = 0, nseq = 0;
+  LzLds Z{nullptr, 0, stage};
+  const int r = sc ? inflate_parse_chunk(L, Z, src, d.src_len, lit_out, seq_out, lit_cap, seq_cap, litn, nseq, lane) : 2;
+  if (lane == 0) {
+    chunks[c].n_items = r ? 0 : nseq;
+    chunks[c].pad = r ? 0 : litn;
+    chunks[c].diag = r ? LZX_DEFERRED : 0;
+  }
+}
