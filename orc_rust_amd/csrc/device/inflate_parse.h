@@ -15,14 +15,16 @@
 // take -- leaves the chunk to the one-wavefront decoder (decompress_deflate_kernel), which is the authority on errors.
 #pragma once
 
+#ifndef INF_SEG
 #define INF_SEG 256u                      // bits per lane and window
+#endif
 #define INF_WIN_BYTES (64u * INF_SEG / 8u)  // 2 KiB
 #define INF_SLACK 16u                     // a token reads at most 48 bits past its first one; a lane stops within them
 
 struct InfLds {
   HuffTab lit, dist;
   uint8_t lens[320];
-  __attribute__((aligned(8))) uint8_t win[INF_WIN_BYTES + INF_SLACK + 16];
+  __attribute__((aligned(16))) uint8_t win[INF_WIN_BYTES + INF_SLACK + 24];
   uint32_t end_pos[65];   // [i + 1]: where lane i's decode ended (bits from the window's first bit); [0]: the window's true start (0)
   uint32_t n_lit[64], n_seq[64], tail_lit[64], carry_in[64];
 };
@@ -54,9 +56,11 @@ __device__ __forceinline__ int inf_slow(uint64_t bits, const HuffTab& h, uint32_
 
 // the token at bit `pos` of the staged window (per lane: no cooperation)
 __device__ __forceinline__ InfTok inf_token(const uint8_t* win, uint32_t pos, const HuffTab& lc, const HuffTab& dc) {
-  uint64_t v;
-  __builtin_memcpy(&v, win + (pos >> 3), 8);
-  v >>= pos & 7;  // >= 57 bits
+  // 57 bits or more from bit `pos` on: two aligned 8-byte reads and a funnel shift (an unaligned 8-byte LDS read is eight byte reads)
+  const uint64_t* w64 = reinterpret_cast<const uint64_t*>(win) + (pos >> 6);
+  const uint64_t w0 = w64[0], w1 = w64[1];
+  const uint32_t sh = pos & 63;
+  uint64_t v = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
   InfTok t{3, 0, 0, 0};
   uint32_t used;
   int sym;
@@ -113,7 +117,7 @@ __device__ __forceinline__ int inf_window(InfLds& L, const uint8_t* src, uint32_
                                           uint32_t& nseq, uint32_t& pending_ll, uint32_t lit_cap, uint32_t seq_cap, uint32_t lane) {
   // ---- stage the window (byte aligned at its first bit's byte) ----
   const uint32_t byte0 = (uint32_t)(bitpos >> 3), bit0 = (uint32_t)(bitpos & 7);
-  for (uint32_t k = lane * 8; k < INF_WIN_BYTES + INF_SLACK + 8; k += 512) {
+  for (uint32_t k = lane * 8; k < INF_WIN_BYTES + INF_SLACK + 16; k += 512) {
     uint64_t v = 0;
     const uint64_t p = (uint64_t)byte0 + k;
     if (p + 8 <= n) v = ld_u64(src + p);
