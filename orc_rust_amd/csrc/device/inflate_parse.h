@@ -21,13 +21,36 @@
 #define INF_WIN_BYTES (64u * INF_SEG / 8u)  // 2 KiB
 #define INF_SLACK 16u                     // a token reads at most 48 bits past its first one; a lane stops within them
 
+// codes longer than the fast table's 10 bits: per length 11..15 the first canonical code, how many there are, and where their symbols
+// start in HuffTab::symbol (filled per block by inf_long_codes)
+struct InfLong {
+  uint16_t first[5], count[5], index[5], pad;
+};
 struct InfLds {
   HuffTab lit, dist;
   uint8_t lens[320];
   __attribute__((aligned(16))) uint8_t win[INF_WIN_BYTES + INF_SLACK + 24];
   uint32_t end_pos[65];   // [i + 1]: where lane i's decode ended (bits from the window's first bit); [0]: the window's true start (0)
   uint32_t n_lit[64], n_seq[64], tail_lit[64], carry_in[64];
+  uint16_t lbase[32], dbase[32];  // RFC 1951 3.2.5 (copies of LBASE / DBASE / LEXT / DEXT: an LDS read, not a trip to memory)
+  uint8_t lext[32], dext[32];
+  InfLong llong, dlong;
 };
+__device__ __forceinline__ void inf_long_codes(InfLong& g, const HuffTab& h, uint32_t lane) {
+  if (lane == 0) {
+    uint32_t code = 0, index = 0;
+    for (int len = 1; len < 16; len++) {
+      // (canonical codes: the first code of a length = (first of the length before + its count) << 1)
+      if (len >= 11) {
+        g.first[len - 11] = (uint16_t)code;
+        g.count[len - 11] = h.count[len];
+        g.index[len - 11] = (uint16_t)index;
+      }
+      code = (code + h.count[len]) << 1;
+      index += h.count[len];
+    }
+  }
+}
 
 struct InfTok {
   uint32_t kind;   // 0 literal, 1 match, 2 end of block, 3 cannot be (the serial decoder decides what it is)
@@ -35,27 +58,23 @@ struct InfTok {
   uint32_t a, b;   // literal: byte; match: length, distance
 };
 
-// canonical decode of a code longer than the fast table's 10 bits (or an unused pattern): -1 = no such code
-__device__ __forceinline__ int inf_slow(uint64_t bits, const HuffTab& h, uint32_t& used) {
-  int code = 0, first = 0, index = 0;
-  for (int len = 1; len < 16; len++) {
-    code |= (int)(bits & 1);
-    bits >>= 1;
-    const int count = h.count[len];
-    if (code - count < first) {
-      used = (uint32_t)len;
-      return h.symbol[index + (code - first)];
+// the code at the low end of `bits` when the fast table has no entry for it (a code of 11..15 bits): -1 = no such code
+__device__ __forceinline__ int inf_slow(uint64_t bits, const HuffTab& h, const InfLong& g, uint32_t& used) {
+  const uint32_t r = __builtin_bitreverse32((uint32_t)bits) >> 17;  // the first 15 bits, the first one on top
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const uint32_t c = r >> (4 - k);  // the first 11 + k bits as a code
+    const uint32_t d = c - g.first[k];
+    if (d < g.count[k]) {
+      used = 11u + (uint32_t)k;
+      return h.symbol[g.index[k] + d];
     }
-    index += count;
-    first += count;
-    first <<= 1;
-    code <<= 1;
   }
   return -1;
 }
 
 // the token at bit `pos` of the staged window (per lane: no cooperation)
-__device__ __forceinline__ InfTok inf_token(const uint8_t* win, uint32_t pos, const HuffTab& lc, const HuffTab& dc) {
+__device__ __forceinline__ InfTok inf_token(const InfLds& L, const uint8_t* win, uint32_t pos, const HuffTab& lc, const HuffTab& dc) {
   // 57 bits or more from bit `pos` on: two aligned 8-byte reads and a funnel shift (an unaligned 8-byte LDS read is eight byte reads)
   const uint64_t* w64 = reinterpret_cast<const uint64_t*>(win) + (pos >> 6);
   const uint64_t w0 = w64[0], w1 = w64[1];
@@ -69,7 +88,7 @@ __device__ __forceinline__ InfTok inf_token(const uint8_t* win, uint32_t pos, co
     used = e >> 12;
     sym = (int)(e & 0xfff);
   } else {
-    sym = inf_slow(v, lc, used);
+    sym = inf_slow(v, lc, L.llong, used);
     if (sym < 0) return t;
   }
   if (sym < 256) {
@@ -85,8 +104,8 @@ __device__ __forceinline__ InfTok inf_token(const uint8_t* win, uint32_t pos, co
   }
   sym -= 257;
   if (sym >= 29) return t;
-  const uint32_t le = LEXT[sym];
-  const uint32_t len = LBASE[sym] + ((uint32_t)(v >> used) & ((1u << le) - 1));
+  const uint32_t le = L.lext[sym];
+  const uint32_t len = L.lbase[sym] + ((uint32_t)(v >> used) & ((1u << le) - 1));
   used += le;
   uint32_t du;
   int ds;
@@ -95,13 +114,13 @@ __device__ __forceinline__ InfTok inf_token(const uint8_t* win, uint32_t pos, co
     du = e >> 12;
     ds = (int)(e & 0xfff);
   } else {
-    ds = inf_slow(v >> used, dc, du);
+    ds = inf_slow(v >> used, dc, L.dlong, du);
     if (ds < 0) return t;
   }
   if (ds >= 30) return t;
   used += du;
-  const uint32_t de = DEXT[ds];
-  const uint32_t dist = DBASE[ds] + ((uint32_t)(v >> used) & ((1u << de) - 1));
+  const uint32_t de = L.dext[ds];
+  const uint32_t dist = L.dbase[ds] + ((uint32_t)(v >> used) & ((1u << de) - 1));
   used += de;
   t.kind = 1;
   t.bits = used;  // <= 15 + 5 + 15 + 13 = 48
@@ -137,12 +156,13 @@ __device__ __forceinline__ int inf_window(InfLds& L, const uint8_t* src, uint32_
   auto run = [&](uint32_t start, bool write, uint32_t lit_base, uint32_t seq_base, uint32_t carry) {
     uint32_t pos = start, flag = 0;
     uint32_t nl = 0, ns = 0, run_ll = carry;
+#pragma unroll 1
     while (pos < seg_end) {
       if ((uint64_t)pos - bit0 >= left) {
         flag = 2;  // ran off the end of the input without an end of block
         break;
       }
-      const InfTok t = inf_token(L.win, pos, L.lit, L.dist);
+      const InfTok t = inf_token(L, L.win, pos, L.lit, L.dist);
       if (t.kind == 3 || (uint64_t)pos - bit0 + t.bits > left) {
         flag = 2;
         break;
@@ -245,6 +265,13 @@ __device__ __forceinline__ int inflate_parse_chunk(InfLds& L, LzLds Z, const uin
   LzIn in{src, n, Z.stage, 0};
   lzin_stage(in, 0, lane);
   BitRd b{src, n, 0, 0, 0, &in};
+  if (lane < 32) {
+    L.lbase[lane] = lane < 29 ? LBASE[lane] : 0;
+    L.lext[lane] = lane < 29 ? LEXT[lane] : 0;
+    L.dbase[lane] = lane < 30 ? DBASE[lane] : 0;
+    L.dext[lane] = lane < 30 ? DEXT[lane] : 0;
+  }
+  wave_sync();
   uint32_t litn = 0, nseq = 0, pending = 0;
   uint32_t last;
   do {
@@ -323,6 +350,9 @@ __device__ __forceinline__ int inflate_parse_chunk(InfLds& L, LzLds Z, const uin
     } else {
       return 2;
     }
+    inf_long_codes(L.llong, L.lit, lane);
+    inf_long_codes(L.dlong, L.dist, lane);
+    wave_sync();
     // ---- the block's tokens, a window at a time ----
     uint64_t bitpos = (uint64_t)b.pos * 8 - b.bc;
     for (;;) {
