@@ -140,24 +140,35 @@ __device__ __forceinline__ bool plausible_header(const uint8_t* data, uint64_t l
   } else {
     if (hn != 128 || hb < 0x80) return false;  // 128 literals
   }
-  uint64_t q = p + hsize;
   const int hops = CODEC == CODEC_RLE2 ? 2 : 3;
-  for (int i = 0; i < hops; i++) {
-    if (q == len) return true;
-    if (q > len) return false;
-    if (bm && q >= wbase && q - wbase < 64ull * RLE_BLK) {
-      uint64_t o = q - wbase;
-      bool set = (bm[o >> 9][(o >> 6) & 7] >> (o & 63)) & 1;
-      if (!set) return false;
-      if (i == hops - 1) return true;
+  auto forward = [&]() -> bool {
+    uint64_t q = p + hsize;
+    for (int i = 0; i < hops; i++) {
+      if (q == len) return true;
+      if (q > len) return false;
+      if (bm && q >= wbase && q - wbase < 64ull * RLE_BLK) {
+        uint64_t o = q - wbase;
+        bool set = (bm[o >> 9][(o >> 6) & 7] >> (o & 63)) & 1;
+        if (!set) return false;
+        if (i == hops - 1) return true;
+      }
+      uint32_t gsize, gn, gerr;
+      hop_parse<CODEC>(data + q, len - q, is_signed, nbits, gsize, gn, gerr);
+      const uint32_t gb = data[q];
+      if (gerr || gn != hn || (CODEC == CODEC_RLE2 ? (gb >> 6) != (hb >> 6) : gb < 0x80)) return false;
+      q += gsize;
     }
-    uint32_t gsize, gn, gerr;
-    hop_parse<CODEC>(data + q, len - q, is_signed, nbits, gsize, gn, gerr);
-    const uint32_t gb = data[q];
-    if (gerr || gn != hn || (CODEC == CODEC_RLE2 ? (gb >> 6) != (hb >> 6) : gb < 0x80)) return false;
-    q += gsize;
+    return true;
+  };
+  if (forward()) return true;
+  // The runs that follow may be of another kind -- a writer that flushes its encoder at row-group boundaries ends every group with
+  // a short run -- while the runs BEFORE are full ones: two DIRECT runs with this header's two bytes (which fix the size) ending
+  // exactly where this one starts are the same evidence, looked at backwards.
+  if (CODEC == CODEC_RLE2 && (hb >> 6) == RT_DIRECT && p >= 2ull * hsize && p + 1 < len) {
+    const uint32_t h2 = ld_u32(data + p) & 0xffffu;
+    return (ld_u32(data + p - hsize) & 0xffffu) == h2 && (ld_u32(data + p - 2ull * hsize) & 0xffffu) == h2;
   }
-  return true;
+  return false;
 }
 
 // Prefilter: bit i of the result = byte i of the 8-byte word `w` may start a full-run header
