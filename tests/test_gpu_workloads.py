@@ -100,3 +100,18 @@ def test_c2_rowgroup_flushes():
     W.check_result(res, cols, expect)
     G.assert_column_parity(res, 0, cols[0], streams, n, 8192, what="c2-rowgroup")
     res.free()
+
+
+def test_zstd_chunks_put_off_by_the_streaming_pass_are_taken_again(monkeypatch):
+    """The Zstandard execution kernel runs beside the entropy kernel; a workgroup that waits too long for sequences puts its chunk
+    off and a second launch behind the entropy kernel takes it.  With no patience at all (ORCGPU_EXEC_PATIENCE=0) that happens to
+    every chunk whose sequences are not there at once: the result must not change."""
+    monkeypatch.setenv("ORCGPU_EXEC_PATIENCE", "0")
+    rows = 400_000
+    table = W.lineitem_table(rows)
+    stripe = W.lineitem_stripe(table, 0, rows, "zstd")
+    res = decode_all([stripe], "zstd")[0]
+    n, cols, streams, expect = stripe
+    assert res.status()[0] == 0, res.status()
+    W.check_result(res, cols, expect)
+    res.free()
