@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- decoded GB/s + Mrows/s into Arrow for the ORC stripe decode hot path.
 
-Default workload = the one BASELINE.json's metric is quoted on, config C4 at single-GPU size: the stripes of a
-TPC-H-shaped `lineitem` table at scale factor 1 (6 001 215 rows, the 16 columns of the reference's
-scripts/convert_tpch.py:46-63: 3 x Int64, Int32, 4 x Decimal128(15,2), 3 x Date32, 4 dictionary Utf8, 1 direct
-Utf8), Zstandard level 3 in 256 KiB chunks, stripes of 2 189 312 rows (what the ORC C++ writer cuts at
-stripe_size = 64 MiB for this table), seeded synthetic data (orc_rust_amd/gen/tpchgen.c: no dbgen in the image).
-A "step" decodes every stripe once: compressed stream bytes are already resident in HBM (staged through the C ABI
-before the timed region), Arrow buffers are left in HBM.
+Default workload = the one BASELINE.json's metric is quoted on, config C4: the stripes of a TPC-H-shaped `lineitem` table
+(the 16 columns of the reference's scripts/convert_tpch.py:46-63: 3 x Int64, Int32, 4 x Decimal128(15,2), 3 x Date32,
+4 dictionary Utf8, 1 direct Utf8), Zstandard level 3 in 256 KiB chunks, stripes of 2 189 312 rows (what the ORC C++ writer
+cuts at stripe_size = 64 MiB for this table), seeded synthetic data (orc_rust_amd/gen/tpchgen.c: no dbgen in the image).
+Size: ONE GPU'S SHARE of C4 -- scale factor 100 over 8 GPUs = SF 12.5 = 75 004 738 rows = 35 stripes per GPU; with
+`--gpus N` the table is N shares (N = 8: the whole SF100 table, 600 037 902 rows), `--sf` overrides the per-GPU size,
+`--scaling strong` keeps the table at its one-GPU size and shards it over the ranks instead.
+A "step" decodes every stripe of the rank once: compressed stream bytes are already resident in HBM (staged through the C
+ABI before the timed region), Arrow buffers are left in HBM.
 
     python bench.py --gpus N --steps K --warmup W [--workload lineitem|c2|c2-direct|c2-delta|c2-arange|c2-adv|c2-rowgroup|c3|c5]
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the ranks
+    are there: WORLD_SIZE = N), or plainly as `python bench.py --gpus N`: bench.py then starts N rank processes itself
+    (fresh children, before anything touches the GPU) and relays rank 0's line.
 
 Prints ONE JSON line (rank 0).  `value` = whole-job decoded GB/s (Arrow bytes out of all ranks / time of the slowest
 rank).  `roofline` prices the dominant phase of the pipeline (HIP events on the decoder's own stream, per phase:
@@ -18,14 +22,17 @@ orcgpu_last_phase_ms) against the HBM peak with the ALGORITHMIC bytes of SURVEY 
 bytes out.  `cpu_baseline` = the CPU oracle (a C port of the reference's algorithm; the Rust reference cannot be
 built here) on a bounded sample of the same stripes on this box's host cores, 1 thread and all cores.
 
-Multi-GPU (`--gpus N`): the path shards with no data-path collective, one process per GPU.  lineitem: the table grows
-with the job (scale factor N: N x 6 001 215 rows, "weak" scaling -- BASELINE's C4 is SF100 over 8 GPUs, and a
-Zstandard stripe decodes no faster when fewer of them share a GPU: its entropy stage is a serial chain per block) and
-is cut into (stripe, column) UNITS spread over the ranks by their Arrow bytes, longest first
-(orc_rust_amd.shard.unit_shard): every rank generates, stages and decodes only its own columns of its own stripes.
-c2 / c3 / c5: STRIPE shard (round robin) of N x the single-GPU row count.  The only exchange is one all-gather (RCCL)
-of {rows x columns decoded, value bytes of the rank's string columns, Arrow bytes, stream bytes, units, error word};
-rank 0 checks that every unit was decoded exactly once and that the row counts add up.
+Checks before timing (lineitem): the first stripe of the rank is compared buffer by buffer with what the generator implies
+(workloads.check_result); EVERY stripe is compared through weighted word sums of its whole Arrow buffers (values, offsets;
+null counts must be zero): the worker process that generated a stripe reduces the expected buffers, torch reduces the
+decoded ones on the device (workloads.buffer_sum / device_sum below) -- nothing of the product is used by the checker.
+
+Multi-GPU (`--gpus N`): the path shards with no data-path collective, one process per GPU.  lineitem: the table is cut
+into (stripe, column) UNITS spread over the ranks by their Arrow bytes, longest first (orc_rust_amd.shard.unit_shard):
+every rank generates (only its columns of only its stripes: the generator draws by counter), stages and decodes its own
+units.  c2 / c3 / c5: STRIPE shard (round robin).  The only exchange is one all-gather (RCCL) of {rows x columns decoded,
+value bytes of the rank's string columns, Arrow bytes, stream bytes, units, error word, milliseconds per step}; rank 0
+checks that every unit was decoded exactly once and that the row counts add up.
 """
 import argparse
 import json
@@ -40,6 +47,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 C2_ROWS, C2_STRIPE_ROWS = 100_000_000, 8_388_608
+C4_SF100_ROWS = 600_037_902  # BASELINE.json configs[3]: TPC-H SF100 lineitem, sharded over 8 GPUs
 PHASE_KERNELS = {
     "decompress": "block decompression of every chunk of the call",
     "decompress_stage1": {"zstd": "zstd_entropy_kernel (FSE sequences + Huffman literals, one wavefront per block)",
@@ -53,38 +61,67 @@ PHASE_KERNELS = {
 }
 
 
+def host_workers(world):
+    """Worker processes this rank may use for host-side set-up (generation, the CPU baseline): its share of the box."""
+    return max(1, (os.cpu_count() or 1) // max(1, world))
+
+
+def lineitem_total_rows(args, world):
+    if args.sf:
+        per = int(round(args.sf * 6_001_215))
+    elif args.rows:
+        per = args.rows
+    else:  # one GPU's share of C4 (SF100 over 8 GPUs); N shares make exactly the SF100 table at N = 8
+        return int(round(C4_SF100_ROWS / 8)) if args.scaling == "strong" else int(round(C4_SF100_ROWS * world / 8))
+    return per if args.scaling == "strong" else per * world
+
+
 def build_workload(args, rank, world):
-    """Returns (stripes, compression, label, shard description).  stripes: [(n_rows, cols, streams, expect)] of THIS rank."""
+    """Returns (stripes, compression, label, shard description, plan).  stripes: [(n_rows, cols, streams, expect, sums)] of THIS rank
+    (expect: the generator's Arrow buffers, kept for the first stripe only at lineitem scale; sums: their reductions)."""
     from orc_rust_amd import shard
     from orc_rust_amd.gen import workloads as W
     wl = args.workload
     if wl == "lineitem":
+        import multiprocessing as mp
+        from orc_rust_amd import gen
         comp = args.compression or "zstd"
-        rows = (args.rows or W.LINEITEM_SF1_ROWS) * world
+        rows = lineitem_total_rows(args, world)
         stripe_rows = [min(W.LINEITEM_STRIPE_ROWS, rows - lo) for lo in range(0, rows, W.LINEITEM_STRIPE_ROWS)]
         units, loads = shard.unit_shard(stripe_rows, W.LINEITEM_ARROW_BYTES_PER_ROW, world)
         mine = units[rank]
-        desc = "all 16 columns of every stripe" if world == 1 else "(stripe, column) units x%d, LPT by Arrow bytes" % world
+        desc = "all 16 columns of every stripe" if world == 1 else "(stripe, column) units x%d, LPT by Arrow bytes (not whole columns: l_comment alone is 18 %% of the bytes)" % world
         by_stripe = {}
         for s_, c_ in mine:
             by_stripe.setdefault(s_, []).append(c_ + 1)
-        names = sorted({W.LINEITEM[c - 1][0] for cs in by_stripe.values() for c in cs})
-        table = W.lineitem_table(rows, 7, names=names) if mine else {}
-        stripes = []
-        for s_ in sorted(by_stripe):
-            lo = s_ * W.LINEITEM_STRIPE_ROWS
-            stripes.append(W.lineitem_stripe(table, lo, lo + stripe_rows[s_], comp, column_ids=by_stripe[s_]))
-        label = ("C4: TPC-H-shaped lineitem stripes, scale factor %d (%d rows, 16 columns: 3 Int64, Int32, 4 Decimal128(15,2), 3 Date32, "
-                 "4 dictionary Utf8, 1 direct Utf8), %s, %d-row stripes" % (world, rows, comp, W.LINEITEM_STRIPE_ROWS))
-        return stripes, comp, label, desc, {"units": mine, "n_stripes": len(stripe_rows), "n_columns": 16, "rows": rows}
-    rows = (args.rows or C2_ROWS) * world
+        order = sorted(by_stripe)
+        tasks = [(s_, stripe_rows[s_], comp, sorted(by_stripe[s_]), 7, k == 0) for k, s_ in enumerate(order)]
+        # every stripe is generated, encoded and compressed by a worker process of its own (this rank's share of the host cores)
+        nproc = min(len(tasks), host_workers(world))
+        if any(16 in t[3] for t in tasks):
+            gen.lib().orcgen_lineitem_warm(7)  # the comment text pool: built once here, inherited by the forked workers
+        t0 = time.perf_counter()
+        if nproc > 1:
+            with mp.get_context("fork").Pool(nproc) as pool:
+                stripes = pool.map(W.lineitem_unit_task, tasks, chunksize=1)
+        else:
+            stripes = [W.lineitem_unit_task(t) for t in tasks]
+        gen_s = time.perf_counter() - t0
+        label = ("C4: TPC-H-shaped lineitem stripes, scale factor %.4g (%d rows, 16 columns: 3 Int64, Int32, 4 Decimal128(15,2), 3 Date32, "
+                 "4 dictionary Utf8, 1 direct Utf8), %s, %d-row stripes%s" % (
+                     rows / 6_001_215, rows, comp, W.LINEITEM_STRIPE_ROWS,
+                     "" if world == 1 else "; %s scaling: %s" % (args.scaling, "the table is %d one-GPU shares" % world if args.scaling == "weak" else "one table over all ranks")))
+        return stripes, comp, label, desc, {"units": mine, "n_stripes": len(stripe_rows), "n_columns": 16, "rows": rows, "load_estimate": loads,
+                                            "gen_s": gen_s, "gen_procs": nproc}
+    per = args.rows or C2_ROWS
+    rows = per if args.scaling == "strong" else per * world
     n_stripes = (rows + C2_STRIPE_ROWS - 1) // C2_STRIPE_ROWS
     mine = shard.stripe_shard(n_stripes, rank, world)
     desc = "all stripes" if world == 1 else "stripe shard x%d (round robin)" % world
     stripes = []
+    t0 = time.perf_counter()
     if wl.startswith("c2"):
         comp = "none"
-        base = 0
         for s in range(n_stripes):
             n = min(C2_STRIPE_ROWS, rows - s * C2_STRIPE_ROWS)
             kind = {"c2": "direct" if s % 2 == 0 else "delta", "c2-direct": "direct", "c2-delta": "delta", "c2-arange": "arange", "c2-adv": "adv", "c2-rowgroup": "rg"}[wl]
@@ -106,17 +143,21 @@ def build_workload(args, rank, world):
         label = "C5: Timestamp(ns), PATCHED_BASE seconds + DIRECT nanoseconds, %d rows, %s, %d stripes" % (rows, comp, n_stripes)
     else:
         raise SystemExit("unknown workload " + wl)
-    return stripes, comp, label, desc, {"units": [(s_, 0) for s_ in mine], "n_stripes": n_stripes, "n_columns": 1, "rows": rows}
+    stripes = [tuple(st) + (None,) for st in stripes]
+    return stripes, comp, label, desc, {"units": [(s_, 0) for s_ in mine], "n_stripes": n_stripes, "n_columns": 1, "rows": rows,
+                                        "load_estimate": [len(shard.stripe_shard(n_stripes, r, world)) for r in range(world)],
+                                        "gen_s": time.perf_counter() - t0, "gen_procs": 1}
 
 
 _TASKS = []  # (n_rows, column, {kind: bytes}, compression): filled before the worker processes are forked
 
 
 def _oracle_stripe(index):
-    """Decodes one (stripe, column) with the CPU oracle, batch by batch; returns (rows, arrow bytes)."""
+    """Decodes one (stripe, column) with the CPU oracle, batch by batch; returns (rows, arrow bytes, seconds)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    n, col, sd, comp = _TASKS[index]
+    n, col, sd, comp = _TASKS[index % len(_TASKS)]
+    t0 = time.perf_counter()
     oc = O.Column(col["orc_type"], col.get("encoding", 2), sd, dictionary_size=col.get("dictionary_size", 0), precision=col.get("precision", 0),
                   scale=col.get("scale", 0), compression=comp)
     assert oc.status == 0
@@ -127,17 +168,17 @@ def _oracle_stripe(index):
         out += len(b["values"]) + (4 * (b["length"] + 1) if b["offsets"] is not None else 0) + (len(b["validity"]) if b["validity"] else 0)
         left -= 8192
     oc.close()
-    return n, out
+    return n, out, time.perf_counter() - t0
 
 
 def cpu_baseline(stripes, comp, budget_s=12.0):
     """CPU oracle (oracle/: C port of the reference's decoders -- the Rust reference cannot be built in this image) on
     the host cores of this box: 1 thread (the reference decodes columns, batches and stripes sequentially) and all
-    cores (one task per (stripe, column)), each on a bounded sample of the same stripes."""
+    cores (one task per (stripe, column), at least four tasks per core), each on a bounded sample of the same stripes."""
     import multiprocessing as mp
     tasks = _TASKS
     del tasks[:]
-    for n, cols, streams, _ in stripes:
+    for n, cols, streams, _, _ in stripes:
         for c in cols:
             sd = {k: (b.tobytes() if isinstance(b, np.ndarray) else bytes(b)) for cid, k, b in streams if cid == c["column_id"]}
             tasks.append((n, {k: v for k, v in c.items()}, sd, comp))
@@ -145,10 +186,14 @@ def cpu_baseline(stripes, comp, budget_s=12.0):
     # 1 thread: whole columns of the first stripe(s) until the budget is used
     t0 = time.perf_counter()
     rows1 = bytes1 = used = 0
+    per_column = {}
     for t in range(len(tasks)):
-        n, ab = _oracle_stripe(t)
+        n, ab, sec = _oracle_stripe(t)
         bytes1 += ab
         used += 1
+        pc = per_column.setdefault(tasks[t][1].get("name", "c%d" % tasks[t][1]["column_id"]), [0, 0.0])
+        pc[0] += ab
+        pc[1] += sec
         if used % ncols == 0:
             rows1 += n
             if time.perf_counter() - t0 > budget_s:
@@ -168,23 +213,110 @@ def cpu_baseline(stripes, comp, budget_s=12.0):
     out = {"value": round(bytes1 / dt1 / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port", "mrows_per_s": round(rows1 / dt1 / 1e6, 3),
            "sample": "%d of %d (stripe, column) tasks of the same workload (%.1f stripes), batch 8192, oracle/liborc_oracle.so; the Rust "
                      "reference itself cannot be built or timed here (no cargo/rustc)" % (used, len(tasks), used / ncols),
-           "cpu_model": model, "host_cores": cores}
+           "cpu_model": model, "host_cores": cores,
+           # where the single thread's time goes: per column, decompression + decode together (the oracle streams)
+           "per_column": {k: {"ms": round(v[1] * 1e3, 1), "GBps": round(v[0] / v[1] / 1e9, 3) if v[1] > 0 else None} for k, v in per_column.items()}}
     if cores > 1:
-        # all cores: as many tasks as ~budget_s of wall time allows at the measured single-thread rate
+        # all cores: at least four tasks per core (the task list is walked round and round if the rank holds fewer), as many
+        # as ~budget_s of wall time allows at the measured single-thread rate
         per_task = dt1 / used
-        ntask = int(min(len(tasks), max(cores, budget_s * cores / per_task)))
-        ntask -= ntask % ncols if ntask >= ncols else 0
-        sel = list(range(max(ntask, min(len(tasks), cores))))
-        sel.sort(key=lambda i: -sum(len(v) for v in tasks[i][2].values()))  # longest first
+        ntask = int(max(4 * cores, min(16 * cores, budget_s * cores / per_task)))
+        sel = list(range(ntask))
+        sel.sort(key=lambda i: -sum(len(v) for v in tasks[i % len(tasks)][2].values()))  # longest first
         with mp.get_context("fork").Pool(cores) as pool:
             pool.map(_oracle_stripe, sel[:cores], chunksize=1)  # start the workers (library load) outside the timed region
             t0 = time.perf_counter()
             res = pool.map(_oracle_stripe, sel, chunksize=1)
             dtn = time.perf_counter() - t0
+        busy = sum(r[2] for r in res)
         out["all_cores"] = {"value": round(sum(r[1] for r in res) / dtn / 1e9, 4), "unit": "GB/s", "cores": cores,
                             "mrows_per_s": round(sum(r[0] for r in res) / ncols / dtn / 1e6, 3),
-                            "sample": "%d (stripe, column) tasks over %d processes" % (len(sel), cores)}
+                            "sample": "%d (stripe, column) tasks (%d distinct) over %d processes, longest first" % (len(sel), min(len(sel), len(tasks)), cores),
+                            "worker_busy_frac": round(busy / (dtn * cores), 3)}
     return out
+
+
+class _DevBytes:
+    """A device range as torch sees it (__cuda_array_interface__): the checker's only view of the result buffers."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, True), "version": 2}
+
+
+def device_sum(torch, ptr, nbytes):
+    """workloads.buffer_sum of nbytes device bytes at ptr, computed by torch on the device: (bytes, weighted word sum mod 2^64)."""
+    if not nbytes:
+        return 0, 0
+    t = torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
+    n8 = nbytes // 8
+    total = 0
+    if n8:
+        w = t[:n8 * 8].view(torch.int64)
+        chunk = 1 << 26
+        for lo in range(0, n8, chunk):
+            hi = min(n8, lo + chunk)
+            k = torch.arange(lo, hi, device="cuda", dtype=torch.int64) * 2 + 1
+            total += int((w[lo:hi] * k).sum().item())
+    if nbytes & 7:
+        tail = bytes(t[n8 * 8:].cpu().numpy().tobytes()) + b"\0" * (8 - (nbytes & 7))
+        total += int.from_bytes(tail, "little") * (2 * n8 + 1)
+    return nbytes, total & ((1 << 64) - 1)
+
+
+def check_sums(torch, res, cols, sums, what):
+    """Every Arrow buffer of a decoded stripe against the sums of the expected ones: the values buffer of a column is one
+    range over all batches (checked to be contiguous), offsets are (batch + 1) entries per batch at a fixed stride."""
+    nb = res.n_batches
+    for ci, c in enumerate(cols):
+        e = sums[c["column_id"]]
+        views = [res.view(b, ci) for b in range(nb)]
+        assert all(v.null_count == 0 and not v.validity for v in views), (what, c.get("name"), "unexpected nulls")
+        at = views[0].values
+        for v in views:
+            assert v.values == at, (what, c.get("name"), "values of the batches are not back to back")
+            at += v.values_bytes
+        got = device_sum(torch, views[0].values, at - views[0].values)
+        assert got == tuple(e["values"]), (what, c.get("name"), "values differ", got, e["values"])
+        if "offsets" in e:
+            stride = (views[1].offsets - views[0].offsets) if nb > 1 else 0
+            assert nb == 1 or all(views[b].offsets == views[0].offsets + b * stride for b in range(nb)), (what, c.get("name"), "offset stride")
+            n_entries = (nb - 1) * (stride // 4) + views[-1].length + 1
+            got = device_sum(torch, views[0].offsets, 4 * n_entries)
+            assert got == tuple(e["offsets"]), (what, c.get("name"), "offsets differ", got, e["offsets"])
+
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` started plainly (no WORLD_SIZE): start the N ranks as fresh child processes -- this process has not
+    touched the GPU and never does --, hand them the rendezvous through the environment, relay rank 0's line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    line = b""
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                break  # a rank failed: the others would wait for it at the next barrier for ever
+            time.sleep(0.2)
+        rc = max((p.poll() or 0) for p in procs if p.poll() is not None) if any(p.poll() for p in procs) else 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()  # exactly the processes started above
+        line = procs[0].stdout.read()
+        for p in procs:
+            p.wait()
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    raise SystemExit(rc)
 
 
 def main():
@@ -195,18 +327,24 @@ def main():
     ap.add_argument("--workload", default="lineitem", choices=["lineitem", "c2", "c2-direct", "c2-delta", "c2-arange", "c2-adv", "c2-rowgroup", "c3", "c5"],
                     help="lineitem (default) = the headline; the others are BASELINE.md's remaining configs, recorded under profiles/")
     ap.add_argument("--compression", default=None, choices=[None, "none", "zstd", "snappy", "lz4", "zlib"])
-    ap.add_argument("--rows", type=int, default=0, help="0 = the config's own size")
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (weak) / of the table (strong); 0 = the config's own size")
+    ap.add_argument("--sf", type=float, default=0.0, help="lineitem: TPC-H scale factor per GPU (weak) / of the table (strong); default 12.5 = one GPU's share of C4's SF100")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every GPU gets a one-GPU share, the table grows with N (N = 8: C4's SF100); strong: one fixed table sharded over the ranks")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--skip-check", action="store_true", help="profiling runs: skip the full-size check (thousands of small D2H copies)")
+    ap.add_argument("--skip-check", action="store_true", help="profiling runs: skip the checks before timing")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        raise SystemExit("bench.py --gpus %d needs %d ranks (WORLD_SIZE=%d): launch it with `python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ...`" % (args.gpus, args.gpus, world, args.gpus, args.gpus))
-    # The workload and the CPU baseline come first: the baseline forks worker processes, which must happen before
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it with `python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ...` or plainly (no WORLD_SIZE) so that it starts "
+                         "its own ranks" % (args.gpus, world, args.gpus, args.gpus))
+    # The workload and the CPU baseline come first: both fork worker processes, which must happen before
     # this process initialises the GPU.
     stripes, comp, label, shard_desc, plan = build_workload(args, rank, world)
     cpu = None
@@ -223,7 +361,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        if torch.cuda.device_count():  # (none: orcgpu_open below reports it)
+            torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -237,11 +376,11 @@ def main():
     # host buffers -> HBM (not part of `value`).  Staged twice: the first pass also pays for the pinned pieces, the copy
     # threads and the arenas (hipHostMalloc / hipMalloc); the second one, timed, finds them in the context's pools -- the
     # state a reader is in from its second stripe on.
-    for s_ in [ctx.stage(n, streams, cols, compression=comp) for n, cols, streams, _ in stripes]:
+    for s_ in [ctx.stage(n, streams, cols, compression=comp) for n, cols, streams, _, _ in stripes]:
         s_.free()
     torch.cuda.synchronize()
     t_stage = time.perf_counter()
-    staged = [ctx.stage(n, streams, cols, compression=comp) for n, cols, streams, _ in stripes]
+    staged = [ctx.stage(n, streams, cols, compression=comp) for n, cols, streams, _, _ in stripes]
     torch.cuda.synchronize()
     t_stage = time.perf_counter() - t_stage
     stream_bytes = sum(s.nbytes() for s in staged)
@@ -254,13 +393,20 @@ def main():
 
     results = ctx.decode(staged) if staged else []
     err_word = 0
-    for (n, cols, streams, expect), res in zip(stripes, results):
+    t_check = time.perf_counter()
+    for k, ((n, cols, streams, expect, sums), res) in enumerate(zip(stripes, results)):
         st = res.status()
         err_word |= st[0]
         assert st[0] == 0, st
-        if not args.skip_check:
-            # full-size check: every decoded Arrow buffer equals what the generated values imply
+        if args.skip_check:
+            continue
+        if expect:
+            # buffer by buffer: every decoded Arrow buffer equals what the generated values imply
             W.check_result(res, cols, expect)
+        if sums is not None:
+            # every stripe: whole-buffer sums, the expected side reduced by the process that generated the stripe
+            check_sums(torch, res, cols, sums, "stripe %d of rank %d" % (k, rank))
+    t_check = time.perf_counter() - t_check
     arrow_bytes = sum(r.arrow_bytes for r in results)
 
     for _ in range(args.warmup):
@@ -276,33 +422,41 @@ def main():
             tot_ms += ctx.timing()[0]
             for k, v in ctx.phase_ms().items():
                 phase[k] += v
+    torch.cuda.synchronize()
+    my_dt = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
     # the way back (outside the timed region, like staging): ONE pinned device-to-host copy per result arena; timed on
-    # the second round, when the pinned host copies exist (the first one allocates them)
-    for r in results:
+    # the second round, when the pinned host copies exist (the first one allocates them).  At table scale a sample of the
+    # stripes is fetched (pinned host memory for every result of a 13 GB table is not what a reader holds either).
+    fetch_n = min(len(results), 4)
+    for r in results[:fetch_n]:
         r.fetch()
     if staged:
-        ctx.decode(staged, results)
+        ctx.decode(staged[:fetch_n], results[:fetch_n])
     t_fetch = time.perf_counter()
-    for r in results:
+    for r in results[:fetch_n]:
         r.fetch()
     t_fetch = time.perf_counter() - t_fetch
-    string_bytes = sum(sum(len(e["values"]) for cid, e in expect.items() if "lengths" in e) for _, _, _, expect in stripes)
-    unit_rows = sum(n * len(cols) for n, cols, _, _ in stripes)  # rows x columns this rank decoded
+    fetch_bytes = sum(r.arrow_bytes for r in results[:fetch_n])
+    string_bytes = sum(sum((len(e["values"]) if "values" in e else 0) for cid, e in expect.items() if "lengths" in e) for _, _, _, expect, _ in stripes)
+    unit_rows = sum(n * len(cols) for n, cols, _, _, _ in stripes)  # rows x columns this rank decoded
+    my_ms = my_dt / args.steps * 1e3
     if dist is not None:
         tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        # the path's only exchange: {rows x columns, value bytes of this rank's string columns, Arrow bytes, stream bytes, units, error word}
-        allc = shard.gather_counts([unit_rows, string_bytes, arrow_bytes, stream_bytes, len(plan["units"]), err_word], dist, coll_dev)
+        # the path's only exchange: {rows x columns, value bytes of this rank's string columns, Arrow bytes, stream bytes, units, error word, us per step}
+        allc = shard.gather_counts([unit_rows, string_bytes, arrow_bytes, stream_bytes, len(plan["units"]), err_word, int(my_ms * 1e3)], dist, coll_dev)
         total_arrow = sum(c[2] for c in allc)
         total_stream = sum(c[3] for c in allc)
         assert all(c[5] == 0 for c in allc), "a rank reported a decode error"
         assert sum(c[4] for c in allc) == plan["n_stripes"] * plan["n_columns"], "every (stripe, column) unit must be decoded exactly once"
         assert sum(c[0] for c in allc) == plan["rows"] * plan["n_columns"], "decoded rows do not add up: %s" % allc
         total_rows = plan["rows"]
-        per_rank = [{"rows_x_columns": c[0], "string_bytes": c[1], "arrow_bytes": c[2], "stream_bytes": c[3], "units": c[4]} for c in allc]
+        tot_load = float(sum(plan["load_estimate"])) or 1.0
+        per_rank = [{"rows_x_columns": c[0], "string_bytes": c[1], "arrow_bytes": c[2], "stream_bytes": c[3], "units": c[4],
+                     "ms_per_step": c[6] / 1e3, "load_estimate_frac": round(plan["load_estimate"][r] / tot_load, 4)} for r, c in enumerate(allc)]
     else:
         total_rows, total_arrow, total_stream = rows, arrow_bytes, stream_bytes
         per_rank = None
@@ -319,23 +473,28 @@ def main():
         dom_kernel = PHASE_KERNELS[dom].get(comp, PHASE_KERNELS["decompress"])
     algo_bytes = stream_bytes + arrow_bytes  # staged stream bytes in + Arrow bytes out (this rank's launch)
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    h2d = stream_bytes / t_stage / 1e9 if t_stage > 0 else None
+    d2h = fetch_bytes / t_fetch / 1e9 if t_fetch > 0 and fetch_bytes else None
+    serial_s = (t_stage + dt / args.steps + (arrow_bytes / (d2h * 1e9) if d2h else 0.0))
     out = {
         "metric": "decoded GB/s + Mrows/s into Arrow, TPC-H lineitem stripe" if args.workload == "lineitem" else "decoded GB/s + Mrows/s into Arrow",
         "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "int64" if args.workload.startswith(("c2", "c5")) else ("u8" if args.workload == "c3" else "int64/i128/u8"),
         "data": "synthetic",
-        "config": {"workload": label, "rows": total_rows, "stripes": len(stripes), "batch_size": 8192, "compression": comp,
+        "config": {"workload": label, "rows": total_rows, "stripes": plan["n_stripes"], "batch_size": 8192, "compression": comp,
                    "parallelism": shard_desc},
         "mrows_per_s": round(total_rows / (dt / args.steps) / 1e6, 1),
         "stream_bytes_in": total_stream, "arrow_bytes_out": total_arrow,
         "device_ms_per_step": round(tot_ms / args.steps, 4),
         "phase_ms": {k: round(v, 4) for k, v in phase.items()},
-        # staging the host stream buffers is outside the timed region; the PCIe-inclusive rate is reported for DESIGN.md only
-        "h2d_stage_ms": round(t_stage * 1e3, 3), "h2d_GBps": round(stream_bytes / t_stage / 1e9, 2) if t_stage > 0 else None,
-        "d2h_fetch_ms": round(t_fetch * 1e3, 3), "d2h_GBps": round(arrow_bytes / t_fetch / 1e9, 2) if t_fetch > 0 else None,
+        # staging the host stream buffers is outside the timed region; the PCIe-inclusive rates are reported for DESIGN.md only
+        "h2d_stage_ms": round(t_stage * 1e3, 3), "h2d_GBps": round(h2d, 2) if h2d else None,
+        "d2h_fetch_sample": "%d of %d stripes" % (fetch_n, len(results)), "d2h_GBps": round(d2h, 2) if d2h else None,
         "pcie_inclusive_GBps": round(arrow_bytes / (t_stage + dt / args.steps) / 1e9, 2),
-        "end_to_end_GBps": round(arrow_bytes / (t_stage + dt / args.steps + t_fetch) / 1e9, 2),
+        "end_to_end_serial_GBps": round(arrow_bytes / serial_s / 1e9, 2),
+        "setup": {"generate_s": round(plan["gen_s"], 2), "generate_procs": plan["gen_procs"], "check_s": round(t_check, 2),
+                  "checked": "skipped" if args.skip_check else ("first stripe buffer by buffer + every stripe by whole-buffer sums" if args.workload == "lineitem" else "every stripe buffer by buffer")},
         "roofline": {"bound": "hbm", "kernel": dom_kernel, "phase": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
                      "kernel_ms": round(dom_ms, 4),
@@ -347,6 +506,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -52,8 +52,9 @@ def lib():
         L.orcgen_free.argtypes = [C.c_void_p]
         L.orcgen_splitmix64.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
         L.orcgen_varint64.argtypes = [C.c_void_p, C.c_size_t, pp, ps]
-        L.orcgen_lineitem.restype = C.c_uint64
-        L.orcgen_lineitem.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.orcgen_lineitem_segment.restype = C.c_uint64
+        L.orcgen_lineitem_segment.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.orcgen_lineitem_warm.argtypes = [C.c_uint64]
         _lib = L
     return _lib
 

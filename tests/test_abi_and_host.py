@@ -2,6 +2,7 @@
 that include/orcgpu.h declares; without a HIP device the product fails loudly instead of falling
 back to a CPU path; the multi-GPU sharding helpers and their only collective (an all-gather of row
 counts) work across two gloo processes."""
+import json
 import os
 import re
 import subprocess
@@ -83,22 +84,45 @@ from orc_rust_amd import shard
 rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 # the multi-rank path of bench.py up to the point where a GPU is needed: this rank's units, their stripes, the all-gather
-args = types.SimpleNamespace(workload="lineitem", rows=30000, compression="none")
+args = types.SimpleNamespace(workload="lineitem", rows=30000, sf=0.0, scaling="weak", compression="none")
 stripes, comp, label, desc, plan = bench.build_workload(args, rank, world)
 assert plan["rows"] == 30000 * world and plan["n_columns"] == 16
-unit_rows = sum(n * len(cols) for n, cols, _, _ in stripes)
-allc = shard.gather_counts([unit_rows, 0, 0, sum(len(b) for _, _, st, _ in stripes for _, _, b in st), len(plan["units"]), 0], dist)
+unit_rows = sum(n * len(cols) for n, cols, _, _, _ in stripes)
+allc = shard.gather_counts([unit_rows, 0, 0, sum(len(b) for _, _, st, _, _ in stripes for _, _, b in st), len(plan["units"]), 0], dist)
 assert sum(c[4] for c in allc) == plan["n_stripes"] * 16
 assert sum(c[0] for c in allc) == plan["rows"] * 16
 allu = [None] * world
 dist.all_gather_object(allu, plan["units"])
 shard.check_unit_coverage(allu, plan["n_stripes"], 16)
 # every rank holds only the columns of its units
-for (n, cols, streams, expect), s_ in zip(stripes, sorted({u[0] for u in plan["units"]})):
+for (n, cols, streams, expect, sums), s_ in zip(stripes, sorted({u[0] for u in plan["units"]})):
     assert sorted(c["column_id"] - 1 for c in cols) == sorted(c for s2, c in plan["units"] if s2 == s_)
+    assert sorted(sums) == sorted(c["column_id"] for c in cols)
+# strong scaling: the table does not grow with the ranks
+args.scaling = "strong"
+assert bench.build_workload(args, rank, world)[4]["rows"] == 30000
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: bench.py starts both ranks itself (fresh children, the parent never
+    touches the GPU), they rendezvous over gloo and get as far as orcgpu_open -- which fails here (no GPU in this
+    container) with the library's own message; on a GPU box the same path carries on to the decode."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "30000", "--compression", "none", "--no-cpu",
+                        "--steps", "1", "--warmup", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = p.stderr.decode()
+    import torch
+    if torch.cuda.is_available():
+        assert p.returncode == 0, err
+        line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and len(line["per_rank"]) == 2 and all(r["ms_per_step"] > 0 for r in line["per_rank"])
+    else:
+        assert p.returncode != 0
+        assert "orcgpu_open" in err and "no usable HIP device" in err, err
 
 
 def test_two_rank_gloo_bench_sharding(tmp_path):
