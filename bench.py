@@ -61,9 +61,35 @@ PHASE_KERNELS = {
 }
 
 
+def usable_cores():
+    """CPU cores this process can actually use: hardware threads, cut down to the scheduler affinity and to the cgroup's CPU
+    quota (a GPU box shows 256 hardware threads to a container whose quota is 16 CPUs: 256 busy processes then run at 1/16
+    speed each, and "256 cores" would overstate the host by 16x)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+        except (OSError, ValueError):
+            pass
+    try:  # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p_ > 0:
+            n = min(n, max(1, int(q / p_ + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def host_workers(world):
-    """Worker processes this rank may use for host-side set-up (generation, the CPU baseline): its share of the box."""
-    return max(1, (os.cpu_count() or 1) // max(1, world))
+    """Worker processes this rank may use for host-side set-up (generation, the CPU baseline): its share of the usable cores."""
+    return max(1, usable_cores() // max(1, world))
 
 
 def lineitem_total_rows(args, world):
@@ -174,7 +200,8 @@ def _oracle_stripe(index):
 def cpu_baseline(stripes, comp, budget_s=12.0):
     """CPU oracle (oracle/: C port of the reference's decoders -- the Rust reference cannot be built in this image) on
     the host cores of this box: 1 thread (the reference decodes columns, batches and stripes sequentially) and all
-    cores (one task per (stripe, column), at least four tasks per core), each on a bounded sample of the same stripes."""
+    USABLE cores (usable_cores(): the cgroup's CPU quota, not the hardware thread count; one task per (stripe, column), at
+    least four tasks per core), each on a bounded sample of the same stripes."""
     import multiprocessing as mp
     tasks = _TASKS
     del tasks[:]
@@ -201,7 +228,7 @@ def cpu_baseline(stripes, comp, budget_s=12.0):
     dt1 = time.perf_counter() - t0
     if used % ncols:
         rows1 += tasks[used - 1][0] * (used % ncols) / ncols
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -213,7 +240,7 @@ def cpu_baseline(stripes, comp, budget_s=12.0):
     out = {"value": round(bytes1 / dt1 / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port", "mrows_per_s": round(rows1 / dt1 / 1e6, 3),
            "sample": "%d of %d (stripe, column) tasks of the same workload (%.1f stripes), batch 8192, oracle/liborc_oracle.so; the Rust "
                      "reference itself cannot be built or timed here (no cargo/rustc)" % (used, len(tasks), used / ncols),
-           "cpu_model": model, "host_cores": cores,
+           "cpu_model": model, "host_cores": cores, "hardware_threads": os.cpu_count(),
            # where the single thread's time goes: per column, decompression + decode together (the oracle streams)
            "per_column": {k: {"ms": round(v[1] * 1e3, 1), "GBps": round(v[0] / v[1] / 1e9, 3) if v[1] > 0 else None} for k, v in per_column.items()}}
     if cores > 1:
@@ -240,7 +267,7 @@ class _DevBytes:
     """A device range as torch sees it (__cuda_array_interface__): the checker's only view of the result buffers."""
 
     def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, True), "version": 2}
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
 def device_sum(torch, ptr, nbytes):

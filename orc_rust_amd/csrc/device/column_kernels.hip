@@ -367,9 +367,11 @@ struct TzJob {
   int offs0;
   int unit;                          // 0 s, 1 ms, 2 us, 3 ns, 4 Decimal128(38, 9)
   uint32_t batch, words_per_batch, pad;
+  long long fold_at;                 // instants at or behind it are looked up whole 400-year cycles earlier (orcgpu_tz.inc: TzTable::fold_at)
 };
 
 __device__ __forceinline__ int tz_offset_at(const TzJob& j, long long sec) {
+  if (sec >= j.fold_at) sec -= ((sec - j.fold_at) / (146097ll * 86400) + 1) * (146097ll * 86400);
   uint32_t lo = 0, hi = j.n_at;
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;

@@ -943,10 +943,13 @@ extern "C" __global__ void __launch_bounds__(256) rle_mend_kernel(RleJob* jobs, 
   if (nb > j->nblocks) nb = j->nblocks;
   uint64_t pos = (uint64_t)lb * RLE_BLK + (lb == 0 ? 0u : blk.exit_[b - 1]);
   uint32_t fill_from = lb, done = 0, last_flag = lb;
-  // what to do at block pb: 0 go on (rewrite it), 1 stop before it (another lane's, or the stretch's strong end)
+  // what to do at block pb: 0 go on (rewrite it), 1 stop before it: the stretch's strong end, or a block that HEADS a stretch of
+  // its own by the test above -- its nearest inconsistent neighbour to the left (last_flag: every block between is visited, so it
+  // is the nearest) is strong or more than RLE_MEND_NEAR blocks away.  Exactly the blocks another lane starts at: ownership of a
+  // block is exclusive, a block's entry / exit / value count are always one lane's.
   auto ends_here = [&](uint32_t pb) -> bool {
     if (pb == lb || !flagged(pb)) return false;
-    if (blk.flags[b0 + pb] || pb - last_flag > RLE_MEND_NEAR) return true;
+    if (blk.flags[b0 + pb] || pb - last_flag > RLE_MEND_NEAR || blk.flags[b0 + last_flag]) return true;
     last_flag = pb;
     return false;
   };

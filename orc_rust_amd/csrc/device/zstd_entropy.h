@@ -477,7 +477,7 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
   const uint32_t b = lit_job ? job - n_blocks : job;
   const uint32_t lane = threadIdx.x;
   PROF_BEGIN();
-  ZBlock B = blocks[b];
+  const ZBlock& B = *glob(blocks + b);  // (read in place: a local copy indexed by `w` below would live in scratch)
   const uint8_t* src = as_global(B.src);
   uint8_t* lit_out = (uint8_t*)as_global((void*)B.lit_out);
   uint32_t* seq_out = (uint32_t*)as_global((void*)B.seq_out);

@@ -643,28 +643,40 @@ int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_sta
     // Stripe::writer_tz (stripe.rs:167-171): the ORC epoch is midnight 2015-01-01 in that zone (timestamp.rs:133-147)
     const std::string name = d->writer_timezone;
     auto it = ctx->zones.find(name);
-    if (it == ctx->zones.end()) {
+    bool have = it != ctx->zones.end();
+    if (!have) {
       auto z = std::make_shared<orcgpu_ctx::Zone>();
       if (!find_timezone(name, z->table)) {
-        set_err(ctx, "writer timezone '%s': not found in the tz database (TZDIR, /usr/share/zoneinfo)", name.c_str());
-        delete s;
-        return ORCGPU_UNSUPPORTED;
+        // only a TIMESTAMP column needs the zone (timestamp.rs:128-147); a stripe without one stages like a zone-less stripe
+        bool needs_zone = false;
+        for (uint32_t k = 0; k < d->n_columns; k++) needs_zone = needs_zone || d->columns[k].orc_type == ORCGPU_T_TIMESTAMP;
+        if (needs_zone) {
+          set_err(ctx, "writer timezone '%s': not in the tz database, or its daylight-saving rule is in a form this reader does not handle "
+                       "(looked in $TZDIR, /usr/share/zoneinfo, /usr/lib/zoneinfo, /usr/share/lib/zoneinfo, /etc/zoneinfo; set TZDIR to "
+                       "the directory of a tz database, e.g. the one of Python's tzdata package)", name.c_str());
+          delete s;
+          return ORCGPU_UNSUPPORTED;
+        }
+      } else {
+        z->epoch = tz_orc_epoch(z->table);
+        const size_t n = z->table.at.size();
+        hipError_t he = hipMalloc((void**)&z->dev, n * 12 + 16);
+        if (he == hipSuccess && n) he = hipMemcpy(z->dev, z->table.at.data(), n * 8, hipMemcpyHostToDevice);
+        if (he == hipSuccess && n) he = hipMemcpy(z->dev + n * 8, z->table.offs.data(), n * 4, hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+          set_err(ctx, "table of time zone '%s' (%zu entries): %s", name.c_str(), n, hipGetErrorString(he));
+          if (z->dev) (void)hipFree(z->dev);
+          delete s;
+          return ORCGPU_HIP_ERROR;
+        }
+        it = ctx->zones.emplace(name, z).first;
+        have = true;
       }
-      z->epoch = tz_orc_epoch(z->table);
-      const size_t n = z->table.at.size();
-      if (hipMalloc((void**)&z->dev, n * 12 + 16) != hipSuccess) {
-        set_err(ctx, "hipMalloc for the table of time zone '%s' failed", name.c_str());
-        delete s;
-        return ORCGPU_HIP_ERROR;
-      }
-      if (n) {
-        HIP_TRY(ctx, hipMemcpy(z->dev, z->table.at.data(), n * 8, hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(z->dev + n * 8, z->table.offs.data(), n * 4, hipMemcpyHostToDevice));
-      }
-      it = ctx->zones.emplace(name, z).first;
     }
-    s->zone = it->second;
-    s->desc.ts_base_seconds = s->zone->epoch;
+    if (have) {
+      s->zone = it->second;
+      s->desc.ts_base_seconds = s->zone->epoch;
+    }
   }
   s->cols.assign(d->columns, d->columns + d->n_columns);
   s->desc.columns = nullptr;
