@@ -209,6 +209,13 @@ int orcgpu_selection_batches(const orcgpu_row_selector* selectors, uint32_t n, u
  * synchronisation.  orcgpu_result_export_batch calls it on demand; the exported batches are views into that copy and
  * keep it alive after orcgpu_result_free. */
 int orcgpu_result_fetch(orcgpu_ctx* ctx, orcgpu_result* r);
+/* The same without the wait: the copies are enqueued on the context's device-to-host stream (behind the work enqueued on the
+ * decode stream so far) and the call returns; the next stripe can be staged and decoded meanwhile.  orcgpu_result_fetch /
+ * _export_batch wait for them; decoding into the result again, selecting on it or freeing it waits too.  With
+ * orcgpu_stage_stripe (which does not wait for its copies either) this is what lets a caller keep three stripes in flight:
+ * staging k + 1, decoding k, copying k - 1 back -- the analogue of the reference's async reader fetching the next stripe
+ * while the current one is consumed (async_arrow_reader.rs:165-280). */
+int orcgpu_result_fetch_async(orcgpu_ctx* ctx, orcgpu_result* r);
 
 /* ---- Arrow C Data Interface export (https://arrow.apache.org/docs/format/CDataInterface.html) ---- */
 struct ArrowSchema;
@@ -243,6 +250,12 @@ int orcgpu_reader_set_timestamp_precision(orcgpu_reader* r, int arrow_target);  
 /* with_row_selection (arrow_reader.rs:113): a selection over the rows of the FILE; every stripe takes its share with
  * RowSelection::split_off, and once no rows are left in the selection later stripes are read whole (arrow_reader.rs:296-308). */
 int orcgpu_reader_set_row_selection(orcgpu_reader* r, const orcgpu_row_selector* selectors, uint32_t n);
+/* Read-ahead: how many decoded stripes the reader may be ahead of the caller (default 2, at most 8; 0 = none: every stripe is
+ * read, staged, decoded and copied back inside the orcgpu_reader_next_batch call that needs it).  With read-ahead a worker
+ * thread of the reader stages stripe k + 1, decodes stripe k and starts its copy back while the caller consumes the batches
+ * of stripe k - 1 (async_arrow_reader.rs:165-280: StreamState::Reading beside the decoding of the current stripe).  The
+ * batches are the same either way.  The context must not be used for other calls while such a reader is open. */
+int orcgpu_reader_set_prefetch(orcgpu_reader* r, uint32_t stripes);
 uint64_t orcgpu_reader_total_rows(const orcgpu_reader* r);                                           /* total_row_count */
 uint32_t orcgpu_reader_stripe_count(const orcgpu_reader* r);
 uint32_t orcgpu_reader_column_count(orcgpu_reader* r);                                               /* projected flat columns */

@@ -497,8 +497,12 @@ int oo_column_next_batch(oo_column* c, uint64_t batch_size, oo_batch* out) {
 }
 
 /* ---- writer time zone (array_decoder/timestamp.rs:236-291, :316-349) ------------------------------------ */
-static int32_t tz_offset(const int64_t* at, const int32_t* offs, uint32_t n_at, int32_t offs0, int64_t sec) {
-  /* chrono-tz: the span whose start is <= the instant (binary search over the zone's timespans) */
+static int32_t tz_offset(const int64_t* at, const int32_t* offs, uint32_t n_at, int32_t offs0, int64_t fold_at, int64_t sec) {
+  /* chrono-tz: the span whose start is <= the instant (binary search over the zone's timespans).  A zone that ends in a
+   * daylight-saving RULE has spans without end; the table lists them up to fold_at, and an instant at or behind fold_at is
+   * looked up whole 400-year cycles earlier (the Gregorian calendar repeats after 146 097 days, and so does every rule that
+   * names a month, a week and a weekday); INT64_MAX for a zone whose last offset holds for ever. */
+  if (sec >= fold_at) sec -= ((sec - fold_at) / (146097ll * 86400) + 1) * (146097ll * 86400);
   uint32_t lo = 0, hi = n_at;
   while (lo < hi) {
     uint32_t mid = lo + (hi - lo) / 2;
@@ -514,7 +518,7 @@ static int64_t floor_div(int64_t a, int64_t b) {
 }
 
 uint64_t oo_timestamps_to_utc(int64_t* values, const uint8_t* validity, uint64_t n, int unit, const int64_t* at, const int32_t* offs,
-                              uint32_t n_at, int32_t offs0, uint8_t* validity_out) {
+                              uint32_t n_at, int32_t offs0, int64_t fold_at, uint8_t* validity_out) {
   /* DateTime::<Utc>::MIN_UTC / MAX_UTC = NaiveDate::MIN (-262143-01-01) 00:00:00 / NaiveDate::MAX (+262142-12-31) 23:59:59.999999999 */
   const int64_t chrono_min = -8334601315200ll, chrono_max = 8210266876799ll;
   uint64_t nulls = 0;
@@ -529,7 +533,7 @@ uint64_t oo_timestamps_to_utc(int64_t* values, const uint8_t* validity, uint64_t
     if (unit == 3) {
       /* writer_tz.timestamp_nanos(ts).naive_local().and_utc().timestamp_nanos_opt() */
       int64_t sec = floor_div(ts, 1000000000);
-      __int128 r = (__int128)ts + (__int128)tz_offset(at, offs, n_at, offs0, sec) * 1000000000;
+      __int128 r = (__int128)ts + (__int128)tz_offset(at, offs, n_at, offs0, fold_at, sec) * 1000000000;
       ok = r <= (__int128)INT64_MAX && r >= (__int128)INT64_MIN;
       out = (int64_t)r;
     } else {
@@ -538,7 +542,7 @@ uint64_t oo_timestamps_to_utc(int64_t* values, const uint8_t* validity, uint64_t
       int64_t m = (int64_t)((uint64_t)ts * (uint64_t)k); /* release build: wrapping */
       int64_t sec = floor_div(m, 1000000);
       ok = sec >= chrono_min && sec <= chrono_max;
-      if (ok) out = (m + (int64_t)tz_offset(at, offs, n_at, offs0, sec) * 1000000) / k;
+      if (ok) out = (m + (int64_t)tz_offset(at, offs, n_at, offs0, fold_at, sec) * 1000000) / k;
     }
     if (ok) {
       values[i] = out;
@@ -551,12 +555,12 @@ uint64_t oo_timestamps_to_utc(int64_t* values, const uint8_t* validity, uint64_t
   return nulls;
 }
 
-void oo_timestamp_decimals_to_utc(uint64_t* values, uint64_t n, const int64_t* at, const int32_t* offs, uint32_t n_at, int32_t offs0) {
+void oo_timestamp_decimals_to_utc(uint64_t* values, uint64_t n, const int64_t* at, const int32_t* offs, uint32_t n_at, int32_t offs0, int64_t fold_at) {
   for (uint64_t i = 0; i < n; i++) {
     __int128 ts = (__int128)(((unsigned __int128)values[2 * i + 1] << 64) | values[2 * i]);
     __int128 q = ts / 1000000000;
     if (ts % 1000000000 < 0) q--; /* div_euclid */
-    __int128 r = ts + (__int128)tz_offset(at, offs, n_at, offs0, (int64_t)q) * 1000000000;
+    __int128 r = ts + (__int128)tz_offset(at, offs, n_at, offs0, fold_at, (int64_t)q) * 1000000000;
     values[2 * i] = (uint64_t)(unsigned __int128)r;
     values[2 * i + 1] = (uint64_t)((unsigned __int128)r >> 64);
   }

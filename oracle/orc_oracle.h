@@ -139,12 +139,13 @@ int oo_column_next_batch(oo_column* c, uint64_t batch_size, oo_batch* out);
 
 /* TimestampOffsetArrayDecoder::next_batch (array_decoder/timestamp.rs:236-291): re-labels n decoded TIMESTAMP values of a
  * batch from the writer's zone to UTC.  The zone is a table of UTC instants `at` (ascending, seconds) from which offset
- * offs[i] (seconds east) holds, offs0 before the first.  validity: the batch's Arrow bitmap or NULL (no nulls); values the
+ * offs[i] (seconds east) holds, offs0 before the first; instants at or behind fold_at are looked up whole 400-year cycles
+ * earlier (a zone ending in a daylight-saving rule; INT64_MAX: the last offset holds for ever).  validity: the batch's Arrow bitmap or NULL (no nulls); values the
  * conversion cannot represent become nulls in validity_out ((n + 7) / 8 bytes, always written).  Returns the null count. */
 uint64_t oo_timestamps_to_utc(int64_t* values, const uint8_t* validity, uint64_t n, int unit, const int64_t* at, const int32_t* offs,
-                              uint32_t n_at, int32_t offs0, uint8_t* validity_out);
+                              uint32_t n_at, int32_t offs0, int64_t fold_at, uint8_t* validity_out);
 /* TimestampNanosecondAsDecimalWithTzDecoder::next_inner (timestamp.rs:316-333) over n i128 values (lo, hi words) */
-void oo_timestamp_decimals_to_utc(uint64_t* values, uint64_t n, const int64_t* at, const int32_t* offs, uint32_t n_at, int32_t offs0);
+void oo_timestamp_decimals_to_utc(uint64_t* values, uint64_t n, const int64_t* at, const int32_t* offs, uint32_t n_at, int32_t offs0, int64_t fold_at);
 void oo_column_free(oo_column* c);
 
 #ifdef __cplusplus

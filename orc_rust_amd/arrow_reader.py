@@ -71,6 +71,12 @@ class ArrowReaderBuilder:
         self._ctx._check(self._ctx.L.orcgpu_reader_set_row_selection(self._h, capi.selector_array(selectors), len(selectors)))
         return self
 
+    def with_prefetch(self, stripes):
+        """Read-ahead of the reader (orcgpu_reader_set_prefetch): decoded stripes it may be ahead of the consumer; 0 = none.
+        The counterpart of choosing ArrowStreamReader (async_arrow_reader.rs) over ArrowReader: the batches are the same."""
+        self._ctx._check(self._ctx.L.orcgpu_reader_set_prefetch(self._h, stripes))
+        return self
+
     def total_row_count(self):
         return self._ctx.L.orcgpu_reader_total_rows(self._h)
 

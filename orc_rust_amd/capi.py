@@ -20,9 +20,9 @@ EXPORTS = [
     "orcgpu_open", "orcgpu_close", "orcgpu_last_error", "orcgpu_version", "orcgpu_stage_stripe", "orcgpu_staged_free",
     "orcgpu_staged_bytes", "orcgpu_decode_staged", "orcgpu_stripe_decode", "orcgpu_result_free", "orcgpu_result_status",
     "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
-    "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_timezone_offsets", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
+    "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_fetch_async", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_timezone_offsets", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
     "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
-    "orcgpu_reader_set_projection", "orcgpu_reader_set_projection_roots", "orcgpu_reader_set_schema", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection",
+    "orcgpu_reader_set_projection", "orcgpu_reader_set_projection_roots", "orcgpu_reader_set_schema", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection", "orcgpu_reader_set_prefetch",
     "orcgpu_reader_total_rows", "orcgpu_reader_stripe_count", "orcgpu_reader_column_count", "orcgpu_reader_column_name",
     "orcgpu_reader_next_batch",
 ]
@@ -137,6 +137,8 @@ def load():
     L.orcgpu_result_batch_view.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(BatchView)]
     L.orcgpu_result_copy_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orcgpu_result_fetch.argtypes = [C.c_void_p, C.c_void_p]
+    L.orcgpu_result_fetch_async.argtypes = [C.c_void_p, C.c_void_p]
+    L.orcgpu_reader_set_prefetch.argtypes = [C.c_void_p, C.c_uint32]
     L.orcgpu_result_select.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RowSelector), C.c_uint32]
     L.orcgpu_selection_batches.argtypes = [C.POINTER(RowSelector), C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                            C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(RowSelector), C.c_uint32, C.POINTER(C.c_uint32)]
@@ -324,6 +326,10 @@ class Result:
     def fetch(self):
         """One device-to-host copy of all the result's Arrow buffers (pinned memory); export_batch then makes views."""
         self.ctx._check(self.ctx.L.orcgpu_result_fetch(self.ctx.h, self.h))
+
+    def fetch_async(self):
+        """Starts that copy and returns (orcgpu_result_fetch_async); fetch() / export_batch() wait for it."""
+        self.ctx._check(self.ctx.L.orcgpu_result_fetch_async(self.ctx.h, self.h))
 
     def export_batch(self, batch):
         """Arrow C Data Interface export -> pyarrow.RecordBatch (zero-copy import of host buffers)."""

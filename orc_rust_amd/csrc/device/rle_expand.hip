@@ -79,14 +79,15 @@ __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, uint32_t lane
   return v;
 }
 
-// ob == 4 under a 64-bit decoder (dictionary keys): values outside 0 ..= i32::MAX are stored as -1 -- no key of that size is
-// valid (DictionaryArray::try_new), and the consumer reports them like any other key out of bounds
+// ob < 8 under a 64-bit decoder (dictionary keys, stored 1 / 2 / 4 bytes wide by the size of the dictionary): values that
+// cannot be a key -- negative, or at / above the all-ones pattern of the key width -- are stored as all ones; no key of that
+// size is valid (DictionaryArray::try_new), and the consumer reports them like any other key out of bounds
 template <bool NARROW = false>
 __device__ __forceinline__ void store_val(void* out, uint32_t ob, uint64_t i, int64_t v) {
   if (ob == 8) ((int64_t*)out)[i] = v;
   else if (ob == 4) ((int32_t*)out)[i] = NARROW && (v < 0 || v > 0x7fffffffll) ? -1 : (int32_t)v;
-  else if (ob == 2) ((int16_t*)out)[i] = (int16_t)v;
-  else ((int8_t*)out)[i] = (int8_t)v;
+  else if (ob == 2) ((int16_t*)out)[i] = NARROW && (v < 0 || v > 0xfffell) ? (int16_t)-1 : (int16_t)v;
+  else ((int8_t*)out)[i] = NARROW && (v < 0 || v > 0xfell) ? (int8_t)-1 : (int8_t)v;
 }
 
 __device__ __forceinline__ bool in_range_n(int64_t v, int nbits) { return trunc_n(v, nbits) == v; }
@@ -334,6 +335,38 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           q0 += 512;
           continue;
         }
+        if (narrow && OB <= 2 && CODEC == CODEC_RLE2 && rend - q0 >= 512 && (L.meta[cur] & 0xff) == RT_DIRECT && ((L.meta[cur] >> 8) & 0xff) <= 8 &&
+            (uint64_t)L.oidx[cur] + (q0 - L.start[cur]) + 512 <= needed) {
+          // dictionary keys of a small dictionary (1 or 2 bytes each, at most 8 bits wide in the stream): 512 values of ONE DIRECT
+          // run, every lane EIGHT consecutive ones -- one 8-byte load (8 x w <= 64 bits; w = 8 is byte aligned, narrower widths
+          // leave room for the up to 7 bits before the first value) and one 8- or 16-byte store instead of eight narrow ones
+          const uint32_t w = (L.meta[cur] >> 8) & 0xff;
+          const uint64_t o0 = L.oidx[cur];
+          const uint32_t i0 = q0 - L.start[cur];
+          const uint64_t bit = (uint64_t)(i0 + 8 * lane) * w;
+          uint64_t raw = __builtin_bswap64(ld_u64(data + L.pay[cur] + (bit >> 3))) << (bit & 7);  // MSB-first bit stream (integer/util.rs:44-218)
+          uint64_t lo = 0, hi = 0;
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            uint64_t v = raw >> (64 - w);  // unsigned, w >= 1: no key is negative
+            raw <<= w;
+            if (OB == 1) {
+              lo |= (v > 0xfe ? 0xffull : v) << (8 * k);
+            } else {
+              if (k < 4) lo |= v << (16 * k);  // (w <= 8: always below the all-ones pattern)
+              else hi |= v << (16 * (k - 4));
+            }
+          }
+          uint8_t* o = (uint8_t*)out + (o0 + i0 + 8 * lane) * OB;
+          if (OB == 1) {
+            __builtin_memcpy(o, &lo, 8);
+          } else {
+            uint64_t pr[2] = {lo, hi};
+            __builtin_memcpy(o, pr, 16);
+          }
+          q0 += 512;
+          continue;
+        }
         if (rend - q0 >= 256) {
           // 256 values of ONE run, 4 per lane
           const uint32_t m = L.meta[cur];
@@ -355,10 +388,16 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           q0 += 256;
           continue;
         }
-        uint32_t q = q0 + lane;
-        if (q < T) {
+        // short runs: 256 values per step, lane l takes values q0 + l, + 64, + 128, + 192 -- each finds its run by bisection over
+        // the run starts, then all four loads are issued together (a step costs one memory round trip, whatever it carries)
+        uint32_t rr[4], ix[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t q = q0 + u * 64 + lane;
+          in[u] = q < T;
           uint32_t r = cur;
-          if (q >= rend) {
+          if (in[u] && q >= L.start[r + 1]) {
             uint32_t l2 = r, h2 = 64;
             while (h2 - l2 > 1) {
               uint32_t mid = (l2 + h2) >> 1;
@@ -367,16 +406,25 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
             }
             r = l2;
           }
-          uint32_t idx = q - L.start[r];
-          uint32_t m = L.meta[r];
-          uint64_t o0 = L.oidx[r];
-          bool bad = false;
-          int64_t v = decode_b1(m & 0xff, (m >> 8) & 0xff, L.base[r], L.delta[r], data + L.pay[r], idx, is_signed, nbits, bad);
-          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[r] - 1);
-          uint64_t oo = o0 + idx;
-          if (oo < needed) store_val<narrow>(out, ob, oo, v);
+          rr[u] = r;
+          ix[u] = in[u] ? q - L.start[r] : 0;
         }
-        q0 += 64;
+        int64_t vv[4];
+        bool badv[4] = {false, false, false, false};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t m = L.meta[rr[u]];
+          vv[u] = in[u] ? decode_b1(m & 0xff, (m >> 8) & 0xff, L.base[rr[u]], L.delta[rr[u]], data + L.pay[rr[u]], ix[u], is_signed, nbits, badv[u]) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (!in[u]) continue;
+          const uint64_t o0 = L.oidx[rr[u]];
+          if (badv[u]) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[rr[u]] - 1);
+          const uint64_t oo = o0 + ix[u];
+          if (oo < needed) store_val<narrow>(out, ob, oo, vv[u]);
+        }
+        q0 += 256;
       }
     }
 
@@ -569,7 +617,11 @@ __device__ __forceinline__ void expand_entry(RleJob* jobs, const uint32_t* group
         if (j->nbits == 64) expand_group<CODEC, 4, 64>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
         else expand_group<CODEC, 4>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
         break;
-      default: expand_group<CODEC, 2>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;
+      case 2:
+        if (j->nbits == 64) expand_group<CODEC, 2, 64>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
+        else expand_group<CODEC, 2>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
+        break;
+      default: expand_group<CODEC, 1, 64>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;  // (one-byte dictionary keys)
     }
   }
   PROF_END();

@@ -118,7 +118,7 @@ __device__ __forceinline__ void batch_base_body(const unsigned long long* charto
 // DictionaryStringArrayDecoder::next_batch (array_decoder/string.rs:204-224) per batch: keys
 // (bounds-checked) -> lengths -> int32 offsets restarting at 0 -> gather of the entries.
 struct DictJob {
-  const int32_t* dense;             // decoded keys of the non-null rows (-1: not a possible key, see store_val)
+  const void* dense;                // decoded keys of the non-null rows, key_bytes wide (all ones: not a possible key, see store_val)
   const unsigned long long* vbits;  // stripe-wide validity words (null: no PRESENT stream)
   const uint32_t* rank;             // non-null rows before each 64-row word
   const int32_t* doff;              // dictionary offsets (dict_n + 1)
@@ -127,12 +127,12 @@ struct DictJob {
   unsigned long long* chartot;      // per-batch byte totals, then (at + n_batches) their exclusive scan
   unsigned long long* err;
   const unsigned long long* dict_err;  // error word of the dictionary itself (bad lengths / short blob): nothing of it may be touched then
-  uint8_t* out_chars;               // value bytes of the column (set for the gather launch)
+  uint8_t* out_chars;               // value bytes of the column (set for the second launch)
   uint64_t* total_out;              // scalar receiving the column's total value bytes
   uint64_t n_rows;
   uint32_t batch, n_batches;
   uint32_t dict_n_idx;              // scalar holding the dictionary size
-  uint32_t pad;
+  uint32_t key_bytes;               // 1 (dictionaries of up to 255 entries), 2 (up to 65 535) or 4
 };
 __device__ __forceinline__ DictJob dict_job(const DictJob* jobs, uint32_t i) {
   DictJob j = jobs[i];  // every pointer in it is device global memory: see as_global()
@@ -149,111 +149,131 @@ __device__ __forceinline__ DictJob dict_job(const DictJob* jobs, uint32_t i) {
   j.total_out = glob(j.total_out);
   return j;
 }
-#ifndef DICT_TILE
-#define DICT_TILE 4096u   // rows per tile (a batch takes several): 256 threads x DICT_PER consecutive rows each
-#endif
-#define DICT_PER (DICT_TILE / 256u)
-#define DICT_DOFF_LDS 2048u
+// key of dense value di; -1 for what the expansion marked as impossible (negative or wider than the key type)
+__device__ __forceinline__ int32_t dict_key(const DictJob& j, uint64_t di) {
+  if (j.key_bytes == 1) {
+    const uint32_t k = static_cast<const uint8_t*>(j.dense)[di];
+    return k == 0xffu ? -1 : (int32_t)k;
+  }
+  if (j.key_bytes == 2) {
+    const uint32_t k = static_cast<const uint16_t*>(j.dense)[di];
+    return k == 0xffffu ? -1 : (int32_t)k;
+  }
+  return static_cast<const int32_t*>(j.dense)[di];
+}
+#define DICT_PER 8u                 // consecutive rows per thread
+#define DICT_TILE (256u * DICT_PER) // rows per tile (a batch takes several)
+#define DICT_DOFF_LDS 2048u         // dictionaries of up to this many entries ...
+#define DICT_BYTES_LDS 8192u        // ... and this many bytes are worked on from LDS
+#define DICT_CHARS_LDS 16384u       // value bytes assembled in LDS per round
+#define DICT_STAGE_MAXLEN 64u       // longer entries go row by row straight to memory
 
-// One workgroup per (batch, column): keys -> lengths -> offsets.  Rows are read coalesced into an
-// LDS tile (padded: thread t then scans entries 32t..32t+31 without bank conflicts), one block scan
-// of the 256 partial sums, offsets written back coalesced.
-extern "C" __global__ void __launch_bounds__(256) dict_rows_kernel(const DictJob* jobs, const uint64_t* scalars) {
-  __shared__ uint32_t lens[DICT_TILE + 256];
-  __shared__ int32_t doffc[DICT_DOFF_LDS + 1];
+// The dictionary's offsets (and, when asked, bytes) in LDS if they fit; returns whether they do.  dict_n = 0 for a dictionary that
+// failed its own checks (negative / overflowing lengths, blob shorter than their sum): the column fails at construction, its
+// offsets are not to be trusted -- every row gets an empty string, nothing is gathered.
+__device__ __forceinline__ bool dict_cache(const DictJob& j, uint64_t dict_n, uint16_t* doffc, uint8_t* dbc, uint32_t* maxlen_s, uint32_t tid) {
+  if (dict_n > DICT_DOFF_LDS) return false;
+  const uint32_t dict_bytes = (uint32_t)j.doff[dict_n];
+  if (dict_bytes > DICT_BYTES_LDS) return false;
+  uint32_t ml = 0;
+  for (uint32_t i = tid; i <= dict_n; i += 256) {
+    const int32_t o = j.doff[i];
+    doffc[i] = (uint16_t)o;
+    if (i < dict_n) {
+      const uint32_t l = (uint32_t)(j.doff[i + 1] - o);
+      ml = l > ml ? l : ml;
+    }
+  }
+  if (dbc)
+    for (uint32_t i = tid * 8; i < dict_bytes; i += 256 * 8) {
+      const uint64_t v = ld_u64(j.dbytes + i);  // (the dictionary stream has ORC_PAD bytes of slack behind it)
+      __builtin_memcpy(dbc + i, &v, 8);
+    }
+  if (maxlen_s) atomicMax(maxlen_s, ml);
+  return true;
+}
+
+// Rows i .. i + cnt - 1 (cnt <= 8) of the column: their validity bits (bit r = row i + r) and the dense index of the first valid one.
+__device__ __forceinline__ uint32_t dict_valid8(const DictJob& j, uint64_t i, uint32_t cnt, uint64_t* d0) {
+  uint32_t bits = 0xffu;
+  *d0 = i;
+  if (j.vbits) {
+    const uint32_t sh = i & 63;
+    const unsigned long long w0 = j.vbits[i >> 6];
+    const unsigned long long w1 = j.vbits[(i + 7) >> 6];  // (at most the word behind the last one: the bitmap has slack, `cnt` masks it)
+    bits = (uint32_t)((w0 >> sh) | (sh ? w1 << (64 - sh) : 0ull)) & 0xffu;
+    *d0 = (uint64_t)j.rank[i >> 6] + __builtin_popcountll(w0 & ((1ull << sh) - 1));
+  }
+  return bits & (cnt >= 8 ? 0xffu : (1u << cnt) - 1u);
+}
+
+// Lengths (and dictionary positions) of 8 consecutive rows: keys of the valid ones are consecutive dense values -- for one-byte
+// keys a single 8-byte load.  A key that is no key (out of bounds, or marked impossible by the expansion) yields length 0 and
+// sets bit r of *bad.
+template <bool CACHED>
+__device__ __forceinline__ void dict_rows8(const DictJob& j, uint32_t bits, uint64_t d0, uint64_t dict_n, const uint16_t* doffc, uint32_t* len, uint32_t* so,
+                                           uint32_t* bad) {
+  uint64_t packed = 0;
+  if (j.key_bytes == 1 && bits) packed = ld_u64(static_cast<const uint8_t*>(j.dense) + d0);  // (the key buffer has slack behind it)
+  uint32_t idx = 0;
+  *bad = 0;
+#pragma unroll
+  for (uint32_t r = 0; r < 8; r++) {
+    len[r] = 0;
+    so[r] = 0;
+    if (!((bits >> r) & 1)) continue;
+    int32_t key;
+    if (j.key_bytes == 1) {
+      const uint32_t k = (uint32_t)(packed >> (8 * idx)) & 0xffu;
+      key = k == 0xffu ? -1 : (int32_t)k;
+    } else {
+      key = dict_key(j, d0 + idx);
+    }
+    idx++;
+    if (key < 0 || (uint64_t)key >= dict_n) {
+      *bad |= 1u << r;
+      continue;
+    }
+    const uint32_t o = CACHED ? (uint32_t)doffc[key] : (uint32_t)j.doff[key];
+    so[r] = o;
+    len[r] = (CACHED ? (uint32_t)doffc[key + 1] : (uint32_t)j.doff[key + 1]) - o;
+  }
+}
+
+// Pass 1, one workgroup per (batch, column): keys bounds-checked (DictionaryArray::try_new) -> the batch's value byte total.
+// Nothing per row is written: the second pass (behind the host's sizing of the character arena) forms the offsets again
+// from the keys -- one byte each for small dictionaries -- instead of reading four bytes per row back.
+extern "C" __global__ void __launch_bounds__(256) dict_totals_kernel(const DictJob* jobs, const uint64_t* scalars) {
+  __shared__ uint16_t doffc[DICT_DOFF_LDS + 2];
   __shared__ uint64_t wsum[4];
-  __shared__ uint64_t tbase[256];
   const DictJob j = dict_job(jobs, blockIdx.y);
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   if (b >= j.n_batches) return;
-  // a dictionary that failed its own checks (negative / overflowing lengths, blob shorter than their sum) fails the
-  // column at construction; its offsets are not to be trusted: every row gets an empty string, nothing is gathered
   const bool dict_ok = *j.dict_err == RLE_NO_ERR;
   const uint64_t dict_n = dict_ok ? scalars[j.dict_n_idx] : 0;
-  const bool cached = dict_n <= DICT_DOFF_LDS;
-  if (cached)
-    for (uint32_t i = tid; i <= dict_n; i += 256) doffc[i] = j.doff[i];
+  const bool cached = dict_cache(j, dict_n, doffc, nullptr, nullptr, tid);
   __syncthreads();
   const uint64_t row0 = (uint64_t)b * j.batch;
   const uint64_t rows = j.n_rows - row0 < j.batch ? j.n_rows - row0 : j.batch;
-  int32_t* out = j.offsets + (uint64_t)b * ((uint64_t)j.batch + 1);
-  uint64_t carry = 0;
-  for (uint64_t t0 = 0; t0 < rows; t0 += DICT_TILE) {
-    const uint32_t tn = rows - t0 < DICT_TILE ? (uint32_t)(rows - t0) : DICT_TILE;
-    // 1. keys and lengths of the tile: eight rows per trip, the loads of all eight issued together
-    //    (validity word + rank, then the key) -- the chain of dependent loads is what this step costs
-    for (uint32_t k0 = tid; k0 < DICT_TILE; k0 += 256 * 8) {
-      unsigned long long word[8];
-      uint32_t rk[8];
-      int32_t v[8];
+  uint64_t sum = 0;
+  for (uint64_t k = (uint64_t)tid * DICT_PER; k < rows; k += DICT_TILE) {
+    const uint32_t cnt = rows - k < DICT_PER ? (uint32_t)(rows - k) : DICT_PER;
+    uint64_t d0;
+    const uint32_t bits = dict_valid8(j, row0 + k, cnt, &d0);
+    uint32_t len[8], so[8], bad;
+    if (cached) dict_rows8<true>(j, bits, d0, dict_n, doffc, len, so, &bad);
+    else dict_rows8<false>(j, bits, d0, dict_n, doffc, len, so, &bad);
+    if (bad && dict_ok) report_err64(j.err, row0 + k + (uint32_t)__builtin_ctz(bad), ORC_E_ARROW);  // (a failed dictionary is what the column reports)
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const uint32_t k = k0 + u * 256;
-        const uint64_t i = row0 + t0 + (k < tn ? k : 0);
-        word[u] = j.vbits ? j.vbits[i >> 6] : ~0ull;
-        rk[u] = j.vbits ? j.rank[i >> 6] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const uint32_t k = k0 + u * 256;
-        const uint64_t i = row0 + t0 + (k < tn ? k : 0);
-        const uint32_t bit = i & 63;
-        const bool valid = k < tn && ((word[u] >> bit) & 1);
-        const uint64_t di = j.vbits ? (uint64_t)rk[u] + __builtin_popcountll(word[u] & ((1ull << bit) - 1)) : i;
-        v[u] = j.dense[valid ? di : 0];
-        if (!valid) v[u] = -1;  // null row (or behind the tile): no key
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const uint32_t k = k0 + u * 256;
-        const uint64_t i = row0 + t0 + k;
-        const bool valid = k < tn && ((word[u] >> (i & 63)) & 1);
-        uint32_t len = 0;
-        if (valid) {
-          if (!dict_ok) {
-            // (the dictionary error is what the column reports)
-          } else if (v[u] < 0 || (uint64_t)v[u] >= dict_n) {
-            report_err64(j.err, i, ORC_E_ARROW);
-          } else {
-            len = cached ? (uint32_t)(doffc[v[u] + 1] - doffc[v[u]]) : (uint32_t)(j.doff[v[u] + 1] - j.doff[v[u]]);
-          }
-        }
-        lens[k + k / DICT_PER] = len;
-      }
-    }
-    __syncthreads();
-    // 2. thread-local exclusive scan of DICT_PER consecutive entries
-    uint64_t run = 0;
-    {
-      const uint32_t base = tid * (DICT_PER + 1);
-      for (uint32_t m = 0; m < DICT_PER; m++) {
-        const uint32_t l = lens[base + m];
-        lens[base + m] = (uint32_t)run;  // < 2^32: checked against i32::MAX per batch below
-        run += l;
-      }
-    }
-    // 3. block scan of the 256 sums
-    uint64_t incl = run;
-    for (int o = 1; o < 64; o <<= 1) {
-      uint64_t t = __shfl_up(incl, o);
-      if ((int)(tid & 63) >= o) incl += t;
-    }
-    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-    __syncthreads();
-    uint64_t wbase = carry;
-    for (uint32_t w = 0; w < (tid >> 6); w++) wbase += wsum[w];
-    tbase[tid] = wbase + incl - run;
-    const uint64_t tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-    // 4. offsets, coalesced
-    for (uint32_t k = tid; k < tn; k += 256) out[t0 + k] = (int32_t)(tbase[k / DICT_PER] + lens[k + k / DICT_PER]);
-    carry += tile_total;
-    __syncthreads();
+    for (uint32_t r = 0; r < 8; r++) sum += len[r];
   }
+  for (int o = 32; o; o >>= 1) sum += __shfl_down(sum, o);
+  if ((tid & 63) == 0) wsum[tid >> 6] = sum;
+  __syncthreads();
   if (tid == 0) {
-    out[rows] = (int32_t)carry;
-    j.chartot[b] = carry;
-    if (carry > 0x7fffffffull) report_err64(j.err, row0, ORC_E_ARROW);
+    const uint64_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    j.chartot[b] = total;
+    if (total > 0x7fffffffull) report_err64(j.err, row0, ORC_E_ARROW);
   }
 }
 
@@ -285,152 +305,127 @@ extern "C" __global__ void __launch_bounds__(256) dict_base_kernel(const DictJob
   if (threadIdx.x == 0) *j.total_out = carry_s;
 }
 
-// One workgroup per (batch, column): the batch's value bytes are assembled in LDS (every thread
-// copies the entries of its rows to their offsets) and written to HBM as one coalesced run; batches
-// whose bytes do not fit go row by row straight to memory.
-#ifndef DICT_CHARS_LDS
-#define DICT_CHARS_LDS 16384u
-#endif
-#define DICT_BYTES_LDS 8192u
-extern "C" __global__ void __launch_bounds__(256) dict_gather2_kernel(const DictJob* jobs, const uint64_t* scalars) {
+// Pass 2, one workgroup per (batch, column): keys -> lengths -> int32 offsets restarting at 0 (string.rs:139-140) AND the
+// batch's value bytes, in one go.  A tile of 2048 rows at a time, thread t working on rows 8t .. 8t+7: their keys are eight
+// consecutive dense values (one load), lengths and their running sums stay in registers, one block scan of the 256 sums places
+// the thread, which writes its 8 offsets as two 16-byte stores.  The tile's value bytes are assembled in LDS from the LDS copy
+// of the dictionary -- a thread's rows are one contiguous run of the output --, DICT_CHARS_LDS bytes per round (a row that
+// straddles two rounds is copied in parts), and leave as 16-byte coalesced stores.  Dictionaries too big for LDS, or with
+// entries longer than DICT_STAGE_MAXLEN, go row by row straight from memory to memory.
+template <bool CACHED>
+__device__ __forceinline__ void dict_emit_body(const DictJob& j, uint64_t dict_n, uint8_t* chars, const uint16_t* doffc, const uint8_t* dbc, uint64_t* wsum,
+                                               bool staged, uint32_t b, uint32_t tid) {
+  const uint64_t row0 = (uint64_t)b * j.batch;
+  const uint64_t rows = j.n_rows - row0 < j.batch ? j.n_rows - row0 : j.batch;
+  int32_t* out = j.offsets + (uint64_t)b * ((uint64_t)j.batch + 1);
+  uint8_t* cout = j.out_chars ? j.out_chars + j.chartot[j.n_batches + b] : nullptr;  // (null: the column has no value bytes at all)
+  uint64_t carry = 0;
+  for (uint64_t t0 = 0; t0 < rows; t0 += DICT_TILE) {
+    const uint64_t k = t0 + (uint64_t)tid * DICT_PER;   // first row of this thread in the batch
+    const uint32_t cnt = k < rows ? (rows - k < DICT_PER ? (uint32_t)(rows - k) : DICT_PER) : 0u;
+    uint32_t len[8], so[8], bad;
+    uint64_t d0 = 0;
+    const uint32_t bits = cnt ? dict_valid8(j, row0 + k, cnt, &d0) : 0u;
+    dict_rows8<CACHED>(j, bits, d0, dict_n, doffc, len, so, &bad);  // (pass 1 reported the keys out of bounds: length 0 here)
+    // exclusive running sums of the thread's lengths, block scan of the 256 thread totals
+    uint32_t ex[8];
+    uint64_t run = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < 8; r++) {
+      ex[r] = (uint32_t)run;  // < 2^32: a batch total above i32::MAX was reported by pass 1
+      run += len[r];
+    }
+    uint64_t incl = run;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint64_t t = __shfl_up(incl, o);
+      if ((int)(tid & 63) >= o) incl += t;
+    }
+    __syncthreads();  // (wsum and chars of the previous tile are no longer read)
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint64_t base = incl - run;
+    for (uint32_t w = 0; w < (tid >> 6); w++) base += wsum[w];
+    const uint64_t tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // offsets: 8 consecutive int32 per thread
+    if (cnt == DICT_PER) {
+      int32_t o8[8];
+#pragma unroll
+      for (uint32_t r = 0; r < 8; r++) o8[r] = (int32_t)(carry + base + ex[r]);
+      __builtin_memcpy(out + k, o8, 32);
+    } else {
+      for (uint32_t r = 0; r < cnt; r++) out[k + r] = (int32_t)(carry + base + ex[r]);
+    }
+    // value bytes
+    if (cout && tile_total) {
+      uint8_t* o8 = cout + carry;
+      if (staged) {
+        for (uint64_t rb = 0; rb < tile_total; rb += DICT_CHARS_LDS) {
+          const uint32_t n = tile_total - rb < DICT_CHARS_LDS ? (uint32_t)(tile_total - rb) : DICT_CHARS_LDS;
+          if (rb) __syncthreads();  // (the previous round has left the stage)
+          if (base + run > rb && base < rb + n) {
+#pragma unroll
+            for (uint32_t r = 0; r < 8; r++) {
+              const uint64_t o = base + ex[r], e = o + len[r];
+              const uint64_t lo = o > rb ? o : rb, hi = e < rb + n ? e : rb + n;
+              if (lo < hi) {
+                const uint8_t* src = dbc + so[r] + (uint32_t)(lo - o);
+                uint8_t* d = chars + (uint32_t)(lo - rb);
+                for (uint32_t q = 0; q < (uint32_t)(hi - lo); q++) d[q] = src[q];
+              }
+            }
+          }
+          __syncthreads();
+          // LDS -> HBM: bytes up to the first 16-byte boundary of the destination one by one, then 16 at a time
+          uint8_t* p8 = o8 + rb;
+          uint32_t head = (uint32_t)((16 - ((uintptr_t)p8 & 15)) & 15);
+          if (head > n) head = n;
+          if (tid < head) p8[tid] = chars[tid];
+          const uint32_t body = (n - head) / 16;
+          for (uint32_t q = tid; q < body; q += 256) {
+            uint64_t v[2];
+            __builtin_memcpy(v, chars + head + q * 16, 16);
+            __builtin_memcpy(p8 + head + (uint64_t)q * 16, v, 16);
+          }
+          const uint32_t done = head + body * 16;
+          if (tid < n - done) p8[done + tid] = chars[done + tid];
+        }
+      } else {
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) {
+          if (!len[r]) continue;
+          const uint8_t* src = j.dbytes + so[r];
+          uint8_t* d = o8 + base + ex[r];
+          uint32_t m = 0;
+          for (; m + 8 <= len[r]; m += 8) {
+            const uint64_t v = ld_u64(src + m);
+            __builtin_memcpy(d + m, &v, 8);
+          }
+          for (; m < len[r]; m++) d[m] = src[m];
+        }
+      }
+    }
+    carry += tile_total;
+  }
+  if (tid == 0) out[rows] = (int32_t)carry;
+}
+
+extern "C" __global__ void __launch_bounds__(256) dict_emit_kernel(const DictJob* jobs, const uint64_t* scalars) {
   __shared__ __attribute__((aligned(16))) uint8_t chars[DICT_CHARS_LDS + 16];
-  __shared__ int32_t doffc[DICT_DOFF_LDS + 1];
-  __shared__ uint8_t dbc[DICT_BYTES_LDS];
+  __shared__ uint16_t doffc[DICT_DOFF_LDS + 2];
+  __shared__ __attribute__((aligned(8))) uint8_t dbc[DICT_BYTES_LDS + 8];
+  __shared__ uint64_t wsum[4];
+  __shared__ uint32_t maxlen_s;
   const DictJob j = dict_job(jobs, blockIdx.y);
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   if (b >= j.n_batches) return;
-  const uint64_t total = j.chartot[b];
-  if (!total || !j.out_chars || *j.dict_err != RLE_NO_ERR) return;
-  const uint64_t row0 = (uint64_t)b * j.batch;
-  const uint32_t rows = (uint32_t)(j.n_rows - row0 < j.batch ? j.n_rows - row0 : j.batch);
-  const int32_t* off = j.offsets + (uint64_t)b * ((uint64_t)j.batch + 1);
-  uint8_t* out = j.out_chars + j.chartot[j.n_batches + b];
-  // small dictionaries are copied to LDS once per workgroup (offsets and bytes)
-  const uint64_t dict_n = scalars[j.dict_n_idx];
-  const uint32_t dict_bytes = dict_n <= DICT_DOFF_LDS ? (uint32_t)j.doff[dict_n] : 0xffffffffu;
-  const bool dcached = dict_n <= DICT_DOFF_LDS && dict_bytes <= DICT_BYTES_LDS;
-  __shared__ uint32_t maxlen_s;
+  const bool dict_ok = *j.dict_err == RLE_NO_ERR;
+  const uint64_t dict_n = dict_ok ? scalars[j.dict_n_idx] : 0;
   if (tid == 0) maxlen_s = 0;
   __syncthreads();
-  if (dcached) {
-    uint32_t ml = 0;
-    for (uint32_t i = tid; i <= dict_n; i += 256) {
-      const int32_t o = j.doff[i];
-      doffc[i] = o;
-      if (i < dict_n) {
-        const uint32_t l = (uint32_t)(j.doff[i + 1] - o);
-        ml = l > ml ? l : ml;
-      }
-    }
-    for (uint32_t i = tid; i < dict_bytes; i += 256) dbc[i] = j.dbytes[i];
-    atomicMax(&maxlen_s, ml);
-    __syncthreads();
-  }
-  // The batch's bytes are assembled in LDS a TILE of rows at a time (as many rows as are certain to fit: the longest entry
-  // bounds a row) and written out as coalesced runs; a dictionary too big for LDS goes row by row straight to memory.
-  const uint32_t maxlen = maxlen_s;
-  const bool staged = dcached && maxlen > 0 && maxlen <= DICT_CHARS_LDS / 1024;  // (longer entries: few rows per tile, the direct path is quicker)
-  if (!staged) {
-    for (uint32_t k0 = tid; k0 < rows; k0 += 256 * 4) {
-      // four rows per trip: offsets, validity words and ranks of all four are requested before any is used, then the keys,
-      // then the dictionary offsets -- four chains of dependent loads side by side
-      uint32_t o[4], e[4], so[4];
-      int32_t key[4];
-      unsigned long long word[4];
-      uint32_t rk[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t k = k0 + u * 256 < rows ? k0 + u * 256 : k0;
-        o[u] = (uint32_t)off[k];
-        e[u] = (uint32_t)off[k + 1];
-        word[u] = j.vbits ? j.vbits[(row0 + k) >> 6] : ~0ull;
-        rk[u] = j.vbits ? j.rank[(row0 + k) >> 6] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t k = k0 + u * 256 < rows ? k0 + u * 256 : k0;
-        const uint64_t i = row0 + k;
-        const uint64_t di = j.vbits ? (uint64_t)rk[u] + __builtin_popcountll(word[u] & ((1ull << (i & 63)) - 1)) : i;
-        key[u] = e[u] != o[u] ? j.dense[di] : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) so[u] = dcached ? (uint32_t)doffc[key[u]] : (uint32_t)j.doff[key[u]];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (k0 + u * 256 >= rows) continue;
-        const uint32_t len = e[u] - o[u];
-        if (!len) continue;
-        uint8_t* d = out + o[u];
-        if (dcached) {
-          const uint8_t* src = dbc + so[u];
-          for (uint32_t m = 0; m < len; m++) d[m] = src[m];
-        } else {
-          const uint8_t* src = j.dbytes + so[u];
-          uint32_t m = 0;
-          for (; m + 8 <= len; m += 8) {
-            uint64_t v = ld_u64(src + m);
-            __builtin_memcpy(d + m, &v, 8);
-          }
-          for (; m < len; m++) d[m] = src[m];
-        }
-      }
-    }
-    return;
-  }
-  const uint32_t tile_rows = DICT_CHARS_LDS / maxlen;  // >= 1024
-  for (uint32_t r0 = 0; r0 < rows; r0 += tile_rows) {
-    const uint32_t r1 = r0 + tile_rows < rows ? r0 + tile_rows : rows;
-    const uint32_t base = (uint32_t)off[r0], n = (uint32_t)off[r1] - base;
-    if (n) {
-      for (uint32_t k0 = r0 + tid; k0 < r1; k0 += 256 * 4) {
-        // four rows per trip: offsets and keys of all four are requested before any is used
-        uint32_t o[4], e[4];
-        int32_t key[4];
-        unsigned long long word[4];
-        uint32_t rk[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const uint32_t k = k0 + u * 256 < r1 ? k0 + u * 256 : k0;
-          o[u] = (uint32_t)off[k];
-          e[u] = (uint32_t)off[k + 1];
-          word[u] = j.vbits ? j.vbits[(row0 + k) >> 6] : ~0ull;
-          rk[u] = j.vbits ? j.rank[(row0 + k) >> 6] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          // the row's key: a row with bytes is a non-null row with a key inside the dictionary (dict_rows_kernel)
-          const uint32_t k = k0 + u * 256 < r1 ? k0 + u * 256 : k0;
-          const uint64_t i = row0 + k;
-          const uint64_t di = j.vbits ? (uint64_t)rk[u] + __builtin_popcountll(word[u] & ((1ull << (i & 63)) - 1)) : i;
-          key[u] = e[u] != o[u] ? j.dense[di] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          if (k0 + u * 256 >= r1) continue;
-          const uint32_t len = e[u] - o[u];
-          if (!len) continue;
-          uint8_t* d = chars + (o[u] - base);
-          const uint8_t* src = dbc + doffc[key[u]];
-          for (uint32_t m = 0; m < len; m++) d[m] = src[m];
-        }
-      }
-      __syncthreads();
-      // LDS -> HBM: bytes up to the first 16-byte boundary of the destination one by one, then 16 at a time
-      uint8_t* o8 = out + base;
-      uint32_t head = (uint32_t)((16 - ((uintptr_t)o8 & 15)) & 15);
-      if (head > n) head = n;
-      if (tid < head) o8[tid] = chars[tid];
-      const uint32_t body = (n - head) / 16;
-      for (uint32_t q = tid; q < body; q += 256) {
-        uint64_t v[2];
-        __builtin_memcpy(v, chars + head + q * 16, 16);
-        __builtin_memcpy(o8 + head + (uint64_t)q * 16, v, 16);
-      }
-      const uint32_t done = head + body * 16;
-      if (tid < n - done) o8[done + tid] = chars[done + tid];
-      __syncthreads();
-    }
-  }
+  const bool cached = dict_cache(j, dict_n, doffc, dbc, &maxlen_s, tid);
+  __syncthreads();
+  if (cached) dict_emit_body<true>(j, dict_n, chars, doffc, dbc, wsum, maxlen_s <= DICT_STAGE_MAXLEN, b, tid);
+  else dict_emit_body<false>(j, dict_n, chars, doffc, dbc, wsum, false, b, tid);
 }
 
 // ---- dictionary lengths -> dictionary offsets (single workgroup; the dictionary is loaded once per stripe)

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -247,6 +248,8 @@ struct orcgpu_ctx {
   // ---- staging pipeline (lane 0 only): a copy stream, two pinned pieces filled by a few host threads while the other one
   // is on its way to HBM, a pool of stripe arenas ----
   hipStream_t copy_stream = nullptr;
+  hipStream_t d2h_stream = nullptr;    // results on their way back to the host (orcgpu_result_fetch_async), beside the next decode
+  hipEvent_t d2h_gate = nullptr;       // "everything enqueued on `stream` so far" for the copies on d2h_stream
   uint8_t* piece[2] = {nullptr, nullptr};
   hipEvent_t piece_ev[2] = {nullptr, nullptr};
   bool piece_used[2] = {false, false};
@@ -327,8 +330,16 @@ struct HostMirror {
   size_t arena_cap[kMaxLanes] = {0, 0, 0, 0}, chars_cap[kMaxLanes] = {0, 0, 0, 0};
   uint8_t* sel = nullptr;  // per-batch buffers of a row selection
   size_t sel_cap = 0;
+  hipEvent_t done = nullptr;  // recorded behind the copies of orcgpu_result_fetch_async
+  bool pending = false;       // ... and not waited for yet
+  void wait() {
+    if (pending && done) (void)hipEventSynchronize(done);
+    pending = false;
+  }
   void unref() {
     if (refs.fetch_sub(1) == 1) {
+      wait();
+      if (done) (void)hipEventDestroy(done);
       if (sel) (void)hipHostFree(sel);
       for (auto p : arena)
         if (p) (void)hipHostFree(p);
@@ -511,6 +522,7 @@ struct ColPlan {
   uint32_t err_idx = 0;       // scalar: finisher error word
   int job_present = -1, job_data = -1, job_length = -1, job_secondary = -1;
   bool is_dict = false;
+  uint32_t key_bytes = 4;             // dictionary keys as the expansion stores them (plan_column_ext)
   uint32_t dictn_idx = 0, dicttotal_idx = 0, dicterr_idx = 0, utf8err_idx = 0;
   uint64_t dictlens_off = 0;
   uint64_t n_term_words = 0, tmask_off = 0, tpop_off = 0, trank_off = 0, ttiles_off = 0;
@@ -605,6 +617,8 @@ void orcgpu_close(orcgpu_ctx* c) {
   for (auto& z : c->zones)
     if (z.second->dev) (void)hipFree(z.second->dev);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
+  if (c->d2h_gate) (void)hipEventDestroy(c->d2h_gate);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->fin_pinned) (void)hipHostFree(c->fin_pinned);
   for (auto& e : c->ev)

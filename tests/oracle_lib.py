@@ -83,9 +83,9 @@ def lib():
         L.oo_column_next_batch.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Batch)]
         L.oo_column_free.argtypes = [C.c_void_p]
         L.oo_timestamps_to_utc.restype = C.c_uint64
-        L.oo_timestamps_to_utc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
+        L.oo_timestamps_to_utc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p]
         L.oo_timestamp_decimals_to_utc.restype = None
-        L.oo_timestamp_decimals_to_utc.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32]
+        L.oo_timestamp_decimals_to_utc.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int64]
         _lib = L
     return _lib
 
@@ -202,7 +202,7 @@ def timestamps_to_utc(res, n, unit, tz):
     vals = np.frombuffer(res["values"], dtype=np.int64).copy()
     vout = np.zeros((n + 7) // 8, dtype=np.uint8)
     vin = res["validity"]
-    nulls = lib().oo_timestamps_to_utc(vals.ctypes.data, vin, n, unit, at.ctypes.data, offs.ctypes.data, len(at), int(tz[2]), vout.ctypes.data)
+    nulls = lib().oo_timestamps_to_utc(vals.ctypes.data, vin, n, unit, at.ctypes.data, offs.ctypes.data, len(at), int(tz[2]), int(tz[3]), vout.ctypes.data)
     out = dict(res)
     out["values"] = vals.tobytes()
     out["null_count"] = nulls
@@ -215,7 +215,7 @@ class Column:
 
     def __init__(self, orc_type, encoding, streams, dictionary_size=0, precision=0, scale=0, ts_unit=3,
                  ts_base=1420070400, compression="none", block_size=262144, tz=None):
-        """tz: (at int64[], offs int32[], offs0) -- the writer's zone; TIMESTAMP batches are then re-labelled to UTC."""
+        """tz: (at int64[], offs int32[], offs0, fold_at) -- the writer's zone (tests/tz_table.py); TIMESTAMP batches are then re-labelled to UTC."""
         L = lib()
         self.tz = tz if orc_type == 9 else None
         self.ts_unit = ts_unit

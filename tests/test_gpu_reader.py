@@ -99,3 +99,82 @@ def test_timestamp_precision_and_errors():
     # ...but readable at microsecond precision
     r = ArrowReaderBuilder.try_new(path, ctx()).with_timestamp_precision("us").build()
     assert sum(b.num_rows for b in r) == 3
+
+
+# ---- read-ahead (orcgpu_reader_set_prefetch): the same batches, three stripes in flight ---------------------------------------
+def _all_batches(path_or_bytes, names, prefetch, batch_size=8192, selection=None):
+    b = ArrowReaderBuilder.try_new(path_or_bytes, ctx()).with_projection(names).with_batch_size(batch_size).with_prefetch(prefetch)
+    if selection is not None:
+        b = b.with_row_selection(selection)
+    return list(b.build())
+
+
+def _same_batches(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x.schema.equals(y.schema) and x.num_rows == y.num_rows and x.equals(y)
+
+
+@pytest.mark.parametrize("prefetch", [1, 2, 4])
+def test_reading_ahead_yields_the_batches_of_the_serial_reader(prefetch):
+    """TestOrcFile.testSeek.orc: 7 stripes.  prefetch 0 reads, stages, decodes and copies back inside next_batch; with
+    read-ahead a worker stages stripe k + 1, decodes k and starts its copy back while k - 1 is consumed
+    (async_arrow_reader.rs:165-280) -- the RecordBatches are the same, one by one."""
+    path = A.data_path("TestOrcFile.testSeek.orc")
+    names = [n for n in flat_names(path)[0]]
+    serial = _all_batches(path, names, 0, 1000)
+    ahead = _all_batches(path, names, prefetch, 1000)
+    _same_batches(serial, ahead)
+    assert sum(b.num_rows for b in ahead) == 32768
+    # ... and under a row selection that is split over the stripes
+    sel = [(100, True), (5000, False), (9000, True), (3, False), (12000, True), (4000, False)]
+    _same_batches(_all_batches(path, names, 0, 777, sel), _all_batches(path, names, prefetch, 777, sel))
+
+
+def _lineitem_orc(tmp_path, rows, stripe_bytes):
+    """A multi-stripe lineitem file written by the ORC C++ writer (PyArrow), Zstandard, dictionary encoding on."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_lineitem
+    import pyarrow.orc as orc
+    from orc_rust_amd.gen import workloads as W
+    t = make_lineitem.arrow_table(W.lineitem_table(rows), rows)
+    path = str(tmp_path / "lineitem.orc")
+    orc.write_table(t, path, compression="zstd", compression_block_size=65536, dictionary_key_size_threshold=0.8, stripe_size=stripe_bytes)
+    return path, t
+
+
+def test_reading_ahead_over_a_multi_stripe_lineitem_file(tmp_path):
+    path, table = _lineitem_orc(tmp_path, 400_000, 1 << 20)  # 10 stripes
+    names = table.schema.names
+    b0 = ArrowReaderBuilder.try_new(path, ctx())
+    n_stripes = b0.stripe_count()
+    assert n_stripes >= 8, n_stripes
+    serial = _all_batches(path, names, 0)
+    ahead = _all_batches(path, names, 2)
+    _same_batches(serial, ahead)
+    got = pa.Table.from_batches(ahead)
+    want = table.cast(got.schema) if got.schema != table.schema else table
+    assert got.equals(want)
+
+
+def test_a_reading_ahead_reader_can_be_dropped_half_way(tmp_path):
+    path = A.data_path("TestOrcFile.testSeek.orc")
+    names = [n for n in flat_names(path)[0]]
+    for _ in range(3):
+        r = ArrowReaderBuilder.try_new(path, ctx()).with_projection(names).with_batch_size(500).with_prefetch(3).build()
+        first = next(iter(r))
+        assert first.num_rows == 500
+        r.close()  # the worker is in the middle of later stripes: it is stopped, its results are freed
+    # the context is usable afterwards
+    assert sum(b.num_rows for b in _all_batches(path, names, 2)) == 32768
+
+
+def test_errors_arrive_in_order_when_reading_ahead():
+    # overflowing_timestamps.orc: DecodeTimestamp in its only stripe, serial and ahead alike
+    path = A.data_path("overflowing_timestamps.orc")
+    for prefetch in (0, 2):
+        r = ArrowReaderBuilder.try_new(path, ctx()).with_prefetch(prefetch).build()
+        with pytest.raises(capi.OrcGpuError) as e:
+            list(r)
+        assert e.value.code == 4

@@ -89,7 +89,7 @@ def test_decimal128_target_of_a_zone(zone):
     res = G.gpu_decode(n, [col], streams, writer_timezone=zone)
     assert res.status()[0] == 0
     base = tz_table.orc_epoch(zone)
-    at, offs, offs0 = tz_table.table(zone)
+    at, offs, offs0, fold_at = tz_table.table(zone)
     want = []
     for s, ns in zip(secs.tolist(), nanos.tolist()):
         sse = s + base
@@ -100,7 +100,7 @@ def test_decimal128_target_of_a_zone(zone):
     for i, v in enumerate(want):
         words[2 * i] = v & (2**64 - 1)
         words[2 * i + 1] = (v >> 64) & (2**64 - 1)
-    O.lib().oo_timestamp_decimals_to_utc(words.ctypes.data, len(want), at.ctypes.data, offs.ctypes.data, len(at), int(offs0))
+    O.lib().oo_timestamp_decimals_to_utc(words.ctypes.data, len(want), at.ctypes.data, offs.ctypes.data, len(at), int(offs0), int(fold_at))
     dense = words.reshape(-1, 2)
     spaced = np.zeros((n, 2), dtype=np.uint64)
     spaced[present] = dense
