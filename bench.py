@@ -312,6 +312,71 @@ def check_sums(torch, res, cols, sums, what):
             assert got == tuple(e["offsets"]), (what, c.get("name"), "offsets differ", got, e["offsets"])
 
 
+def pipelined_end_to_end(ctx, stripes, comp, group=4, passes=2):
+    """Host buffers in, host (pinned) Arrow buffers out, with three things in flight at once -- what the read-ahead reader does
+    (orcgpu_reader_set_prefetch; the reference: async_arrow_reader.rs:165-280): a second thread stages the stripes to come
+    (orcgpu_stage_stripe: host copies into pinned pieces + H2D on the copy stream), this thread decodes `group` staged
+    stripes per call (one stripe alone leaves most of the GPU idle: its longest Zstandard block chains bound the call) and
+    starts their copies back (orcgpu_result_fetch_async, device-to-host stream), then waits for the copies of the group
+    before.  Three sets of results are used in turn: from the fourth group on nothing is allocated.
+    Returns (seconds of the last pass, Arrow bytes) -- never part of `value`."""
+    import queue
+    import threading
+    ring = [None, None, None]
+    dt = arrow = 0
+    for _ in range(passes):  # the first pass allocates the arenas and the pinned host copies
+        arrow = 0
+        q = queue.Queue(maxsize=2 * group)
+        failure = []
+
+        def stager():
+            try:
+                for n_, cols_, streams_, _, _ in stripes:
+                    q.put(ctx.stage(n_, streams_, cols_, compression=comp))
+            except Exception as e:  # noqa: BLE001 -- handed to the main thread
+                failure.append(e)
+            q.put(None)
+        t0 = time.perf_counter()
+        th = threading.Thread(target=stager)
+        th.start()
+        g, prev, more = 0, None, True
+        while more:
+            batch = []
+            while len(batch) < group:
+                item = q.get()
+                if item is None:
+                    more = False
+                    break
+                batch.append(item)
+            if not batch:
+                break
+            slot = ring[g % 3] or []
+            res = ctx.decode(batch, [slot[i] if i < len(slot) else None for i in range(len(batch))])
+            ring[g % 3] = res + slot[len(batch):]  # (a shorter last group leaves the rest of its set alone)
+            for st in batch:
+                st.free()
+            for r in res:
+                assert r.status()[0] == 0
+                arrow += r.arrow_bytes
+                r.fetch_async()
+            if prev is not None:
+                for r in prev:
+                    r.fetch()  # the group before is complete on the host: a consumer would read it now
+            prev = res
+            g += 1
+        if prev is not None:
+            for r in prev:
+                r.fetch()
+        dt = time.perf_counter() - t0
+        th.join()
+        if failure:
+            raise failure[0]
+    for slot in ring:
+        for r in slot or []:
+            r.free()
+    return dt, arrow
+
+
 def spawn_ranks(args):
     """`bench.py --gpus N` started plainly (no WORLD_SIZE): start the N ranks as fresh child processes -- this process has not
     touched the GPU and never does --, hand them the rendezvous through the environment, relay rank 0's line."""
@@ -360,6 +425,7 @@ def main():
                     help="weak (default): every GPU gets a one-GPU share, the table grows with N (N = 8: C4's SF100); strong: one fixed table sharded over the ranks")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--skip-check", action="store_true", help="profiling runs: skip the checks before timing")
+    ap.add_argument("--no-e2e", action="store_true", help="profiling runs: skip the pipelined host-to-host measurement behind the timed region")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -500,6 +566,7 @@ def main():
         dom_kernel = PHASE_KERNELS[dom].get(comp, PHASE_KERNELS["decompress"])
     algo_bytes = stream_bytes + arrow_bytes  # staged stream bytes in + Arrow bytes out (this rank's launch)
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    e2e_dt, e2e_bytes = pipelined_end_to_end(ctx, stripes, comp) if len(stripes) >= 2 and not args.no_e2e else (0.0, 0)
     h2d = stream_bytes / t_stage / 1e9 if t_stage > 0 else None
     d2h = fetch_bytes / t_fetch / 1e9 if t_fetch > 0 and fetch_bytes else None
     serial_s = (t_stage + dt / args.steps + (arrow_bytes / (d2h * 1e9) if d2h else 0.0))
@@ -520,6 +587,10 @@ def main():
         "d2h_fetch_sample": "%d of %d stripes" % (fetch_n, len(results)), "d2h_GBps": round(d2h, 2) if d2h else None,
         "pcie_inclusive_GBps": round(arrow_bytes / (t_stage + dt / args.steps) / 1e9, 2),
         "end_to_end_serial_GBps": round(arrow_bytes / serial_s / 1e9, 2),
+        # host stream buffers in, pinned host Arrow buffers out: a staging thread, four stripes per decode call, copies back on
+        # their own stream (stage k + 1 / decode k / copy back k - 1 overlap): measured, see pipelined_end_to_end
+        "end_to_end_GBps": round(e2e_bytes / e2e_dt / 1e9, 2) if e2e_dt > 0 else None,
+        "end_to_end_ms_per_stripe": round(e2e_dt / len(stripes) * 1e3, 3) if e2e_dt > 0 else None,
         "setup": {"generate_s": round(plan["gen_s"], 2), "generate_procs": plan["gen_procs"], "check_s": round(t_check, 2),
                   "checked": "skipped" if args.skip_check else ("first stripe buffer by buffer + every stripe by whole-buffer sums" if args.workload == "lineitem" else "every stripe buffer by buffer")},
         "roofline": {"bound": "hbm", "kernel": dom_kernel, "phase": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,

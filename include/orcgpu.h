@@ -14,7 +14,8 @@
  *
  * Everything below is plain C: pointers, sizes and POD structs; no C++/torch types.
  * Threading: a context is thread-compatible (one thread at a time, may migrate), like
- * `ArrayBatchDecoder: Send` (array_decoder/mod.rs:61).  One HIP stream per context.
+ * `ArrayBatchDecoder: Send` (array_decoder/mod.rs:61) -- with one exception that pipelines need: orcgpu_stage_stripe may run
+ * in one thread while another one decodes / fetches / frees on the same context.
  */
 #ifndef ORCGPU_H
 #define ORCGPU_H
@@ -250,10 +251,11 @@ int orcgpu_reader_set_timestamp_precision(orcgpu_reader* r, int arrow_target);  
 /* with_row_selection (arrow_reader.rs:113): a selection over the rows of the FILE; every stripe takes its share with
  * RowSelection::split_off, and once no rows are left in the selection later stripes are read whole (arrow_reader.rs:296-308). */
 int orcgpu_reader_set_row_selection(orcgpu_reader* r, const orcgpu_row_selector* selectors, uint32_t n);
-/* Read-ahead: how many decoded stripes the reader may be ahead of the caller (default 2, at most 8; 0 = none: every stripe is
- * read, staged, decoded and copied back inside the orcgpu_reader_next_batch call that needs it).  With read-ahead a worker
- * thread of the reader stages stripe k + 1, decodes stripe k and starts its copy back while the caller consumes the batches
- * of stripe k - 1 (async_arrow_reader.rs:165-280: StreamState::Reading beside the decoding of the current stripe).  The
+/* Read-ahead: how many decoded stripes the reader may be ahead of the caller (default 4, at most 8; 0 = none: every stripe is
+ * read, staged, decoded and copied back inside the orcgpu_reader_next_batch call that needs it).  With read-ahead two threads
+ * of the reader work beside the caller: one reads and stages the stripes to come, one decodes the stripes staged so far
+ * (several per call when decoding is the slower side) and starts their copies back, while the caller consumes the batches of
+ * an earlier stripe (async_arrow_reader.rs:165-280: StreamState::Reading beside the decoding of the current stripe).  The
  * batches are the same either way.  The context must not be used for other calls while such a reader is open. */
 int orcgpu_reader_set_prefetch(orcgpu_reader* r, uint32_t stripes);
 uint64_t orcgpu_reader_total_rows(const orcgpu_reader* r);                                           /* total_row_count */

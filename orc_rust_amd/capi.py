@@ -230,9 +230,8 @@ class Context:
         sarr = (C.c_void_p * n)(*[s.h for s in staged_list])
         rarr = (C.c_void_p * n)(*[(r.h if r is not None else None) for r in (results or [None] * n)])
         self._check(self.L.orcgpu_decode_staged(self.h, sarr, n, rarr))
-        if results:
-            return results
-        return [Result(self, rarr[i]) for i in range(n)]
+        # (results[i] given: its buffers were decoded into again; None: a new result)
+        return [results[i] if results and results[i] is not None else Result(self, rarr[i]) for i in range(n)]
 
     def timing(self):
         a, b, c = C.c_float(), C.c_float(), C.c_uint32()

@@ -30,6 +30,7 @@
 
 struct WaveLds {
   uint32_t start[65];
+  uint32_t cstart[65];  // narrow keys: first 8-value chunk of every run slot (see the chunk pass of expand_group)
   uint32_t meta[64];    // type | width << 8 | n << 16
   uint32_t meta2[64];   // pw | pl << 8 | cw << 16
   uint32_t oidx[64];    // output index of the run's first value
@@ -217,7 +218,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
     h.err = 0;
     h.type = 0;
     bool is_b2 = false;
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, chunks = 0;
     if (has) {
       const uint64_t soi = L.soi[lane];
       run_parse<CODEC, true>(data + sp, len - sp, is_signed, nbits, h);
@@ -232,6 +233,11 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
       } else {
         is_b2 = (h.type == RT_DELTA && h.width != 0) || h.type == RT_PATCHED || h.type == RT_V1_LIT;
         cnt = is_b2 ? 0 : h.n;
+        // narrow dictionary keys: bit-packed runs of at most 8 bits a value and repeats leave in chunks of 8 values (below)
+        if (narrow && OB <= 2 && CODEC == CODEC_RLE2 && ((h.type == RT_DIRECT && h.width <= 8) || h.type == RT_SR)) {
+          chunks = (h.n + 7) >> 3;
+          cnt = 0;
+        }
       }
       L.meta[lane] = h.type | (h.width << 8) | (h.n << 16);
       L.oidx[lane] = (uint32_t)soi;
@@ -249,6 +255,67 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
     if (lane == 63) L.start[64] = T;
     wave_sync();
     PROF_MARK(12);
+
+    // ---- narrow keys (dictionary keys stored 1 or 2 bytes wide): the memory instructions are what a short run costs, so a
+    // lane takes EIGHT consecutive values of a run -- one 8-byte load (8 x w <= 64 bits; w = 8 is byte aligned, narrower widths
+    // leave room for the up to 7 bits in front of the first value), one 8- or 16-byte store -- and 64 such chunks of any mix
+    // of runs leave per step ------------------------------------------------------------------------------------------------
+    if (narrow && OB <= 2 && CODEC == CODEC_RLE2) {
+      const uint32_t cincl = wave_incl_scan_u32(chunks, lane);
+      L.cstart[lane] = cincl - chunks;
+      const uint32_t CT = __shfl(cincl, 63);
+      if (lane == 63) L.cstart[64] = CT;
+      wave_sync();
+      for (uint32_t c0 = 0; c0 < CT; c0 += 64) {
+        const uint32_t q = c0 + lane;
+        if (q >= CT) continue;
+        uint32_t l2 = 0, h2 = 64;
+        while (h2 - l2 > 1) {
+          const uint32_t mid = (l2 + h2) >> 1;
+          if (L.cstart[mid] <= q) l2 = mid;
+          else h2 = mid;
+        }
+        const uint32_t r = l2, m = L.meta[r];
+        const uint32_t w = (m >> 8) & 0xff, n = m >> 16, i0 = 8 * (q - L.cstart[r]);
+        const uint32_t nv = n - i0 < 8 ? n - i0 : 8;
+        constexpr uint64_t none = OB == 1 ? 0xffull : 0xffffull;  // "not a key" (store_val)
+        uint64_t lo = 0, hi = 0;
+        if ((m & 0xff) == RT_SR) {
+          const int64_t b = L.base[r];
+          const uint64_t v = b < 0 || (uint64_t)b >= none ? none : (uint64_t)b;
+          lo = v * (OB == 1 ? 0x0101010101010101ull : 0x0001000100010001ull);
+          hi = lo;
+        } else {
+          const uint64_t bit = (uint64_t)i0 * w;
+          uint64_t raw = __builtin_bswap64(ld_u64(data + L.pay[r] + (bit >> 3))) << (bit & 7);  // MSB-first bit stream (integer/util.rs:44-218)
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            uint64_t v = raw >> (64 - w);  // unsigned, 1 <= w <= 8
+            raw <<= w;
+            if (v >= none) v = none;
+            if (OB == 1) lo |= v << (8 * k);
+            else if (k < 4) lo |= v << (16 * k);
+            else hi |= v << (16 * (k - 4));
+          }
+        }
+        const uint64_t oo = (uint64_t)L.oidx[r] + i0;
+        uint8_t* o = (uint8_t*)out + oo * OB;
+        if (nv == 8 && oo + 8 <= needed) {
+          if (OB == 1) {
+            __builtin_memcpy(o, &lo, 8);
+          } else {
+            uint64_t pr[2] = {lo, hi};
+            __builtin_memcpy(o, pr, 16);
+          }
+        } else {
+          for (uint32_t k = 0; k < nv && oo + k < needed; k++) {
+            const uint64_t v = OB == 1 ? (lo >> (8 * k)) & 0xff : ((k < 4 ? lo >> (16 * k) : hi >> (16 * (k - 4))) & 0xffff);
+            if (OB == 1) o[k] = (uint8_t)v;
+            else ((uint16_t*)o)[k] = (uint16_t)v;
+          }
+        }
+      }
+    }
 
     // ---- B1: value-parallel expansion of the random-access runs -----------------------------
     {
@@ -332,38 +399,6 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
             __builtin_memcpy((int64_t*)out + o0 + i0 + u * 128 + 2 * lane, pr, 16);
           }
           if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[cur] - 1);
-          q0 += 512;
-          continue;
-        }
-        if (narrow && OB <= 2 && CODEC == CODEC_RLE2 && rend - q0 >= 512 && (L.meta[cur] & 0xff) == RT_DIRECT && ((L.meta[cur] >> 8) & 0xff) <= 8 &&
-            (uint64_t)L.oidx[cur] + (q0 - L.start[cur]) + 512 <= needed) {
-          // dictionary keys of a small dictionary (1 or 2 bytes each, at most 8 bits wide in the stream): 512 values of ONE DIRECT
-          // run, every lane EIGHT consecutive ones -- one 8-byte load (8 x w <= 64 bits; w = 8 is byte aligned, narrower widths
-          // leave room for the up to 7 bits before the first value) and one 8- or 16-byte store instead of eight narrow ones
-          const uint32_t w = (L.meta[cur] >> 8) & 0xff;
-          const uint64_t o0 = L.oidx[cur];
-          const uint32_t i0 = q0 - L.start[cur];
-          const uint64_t bit = (uint64_t)(i0 + 8 * lane) * w;
-          uint64_t raw = __builtin_bswap64(ld_u64(data + L.pay[cur] + (bit >> 3))) << (bit & 7);  // MSB-first bit stream (integer/util.rs:44-218)
-          uint64_t lo = 0, hi = 0;
-#pragma unroll
-          for (int k = 0; k < 8; k++) {
-            uint64_t v = raw >> (64 - w);  // unsigned, w >= 1: no key is negative
-            raw <<= w;
-            if (OB == 1) {
-              lo |= (v > 0xfe ? 0xffull : v) << (8 * k);
-            } else {
-              if (k < 4) lo |= v << (16 * k);  // (w <= 8: always below the all-ones pattern)
-              else hi |= v << (16 * (k - 4));
-            }
-          }
-          uint8_t* o = (uint8_t*)out + (o0 + i0 + 8 * lane) * OB;
-          if (OB == 1) {
-            __builtin_memcpy(o, &lo, 8);
-          } else {
-            uint64_t pr[2] = {lo, hi};
-            __builtin_memcpy(o, pr, 16);
-          }
           q0 += 512;
           continue;
         }

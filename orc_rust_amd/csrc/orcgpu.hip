@@ -255,6 +255,10 @@ struct orcgpu_ctx {
   bool piece_used[2] = {false, false};
   int piece_next = 0;
   std::vector<std::pair<uint8_t*, size_t>> arena_pool;  // freed staged arenas (device pointer, bytes)
+  // Staging (orcgpu_stage_stripe: copy stream, pinned pieces, zone tables) and decoding (everything else) may run in two
+  // threads at once -- the read-ahead reader stages stripe k + 1 while stripe k is decoded; what the two share is guarded here:
+  std::mutex pool_m;   // arena_pool (taken from by staging, given back to by orcgpu_staged_free)
+  std::mutex err_m;    // `err`
   struct CopyPool* copiers = nullptr;
   // writer time zones seen so far (lane 0 only): host table + its copy in HBM ({at[n] i64}{offs[n] i32})
   struct Zone {
@@ -381,7 +385,10 @@ void set_err(orcgpu_ctx* c, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (c) c->err = buf;
+  if (c) {
+    std::lock_guard<std::mutex> g(c->err_m);
+    c->err = buf;
+  }
 }
 
 #define HIP_TRY(ctx, expr)                                                              \
@@ -711,6 +718,7 @@ int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_sta
   // ---- arena: from the pool (smallest that fits, at most twice the size) or a new allocation ----
   {
     int best = -1;
+    std::unique_lock<std::mutex> pool_guard(ctx->pool_m);
     for (size_t k = 0; k < ctx->arena_pool.size(); k++)
       if (ctx->arena_pool[k].second >= s->dev_bytes && ctx->arena_pool[k].second <= 2 * s->dev_bytes + (1u << 20) &&
           (best < 0 || ctx->arena_pool[k].second < ctx->arena_pool[best].second))
@@ -822,6 +830,7 @@ void orcgpu_staged_free(orcgpu_staged* s) {
   if (s->dev) {
     // back to the pool (decodes that used the stripe have returned: they end with a stream synchronisation)
     orcgpu_ctx* c = s->ctx;
+    std::lock_guard<std::mutex> pool_guard(c->pool_m);
     size_t pooled = 0;
     for (auto& a : c->arena_pool) pooled += a.second;
     if (c->arena_pool.size() < 64 && pooled + s->dev_cap <= (8ull << 30)) c->arena_pool.push_back({s->dev, s->dev_cap});
