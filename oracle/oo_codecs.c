@@ -289,6 +289,124 @@ long oo_lz4_block(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * LZO1X (compression.rs:174-183: lzokay_native::decompress_all; lzokay-native "0.1" is a port of lzokay's
+ * decompress(), itself written from the format description in the Linux kernel, Documentation/staging/lzo.rst).
+ * The crate is absent from /root/reference (Cargo.toml:44): the algorithm is restated from the format --
+ *   first byte 18..21: 1..4 "state" literals follow, >= 22: (byte - 17) literals, state 4;
+ *   instructions  1LLDDDSS / 01LDDDSS + H      M2: length (inst >> 5) + 1, distance (H << 3) + D + 1
+ *                 001LLLLL [+ zero bytes + byte] + LE16   M3: length 2 + L (L = 0: 31 + 255 z + byte), distance (LE16 >> 2) + 1
+ *                 0001HLLL [+ zero bytes + byte] + LE16   M4: length 2 + L (L = 0: 7 + 255 z + byte), distance 16384 + (H << 14) + (LE16 >> 2);
+ *                                                          distance 16384 ends the stream
+ *                 0000xxxx                                 by the state: 0 -> literal run of 3 + L (L = 0: 15 + 255 z + byte), state 4;
+ *                                                          1..3 -> 2 bytes from (inst >> 2) + (H << 2) + 1; 4 -> 3 bytes from (inst >> 2) + (H << 2) + 2049
+ *   S (two low bits of the instruction / of the LE16): that many literals follow the match and become the state.
+ * Every failure of the crate (input overrun, output overrun, look-behind before the output, a stream that does not end with
+ * the M4 marker, input left over) is an Err: BuildLzoDecoder.  Pinned by the reference's two LZO fixture files
+ * (tests/golden/data/alltypes.lzo.orc, TestVectorOrcFile.testLzo.orc).
+ * ---------------------------------------------------------------------------------------- */
+long oo_lzo1x(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+  size_t ip = 0, op = 0, state = 0, nstate = 0, lblen = 0, lbdist = 0;
+  if (n < 3) return -1;
+#define LZO_IN(k) do { if (n - ip < (size_t)(k)) return -1; } while (0)
+#define LZO_OUT(k) do { if (cap - op < (size_t)(k)) return -1; } while (0)
+#define LZO_ZEROS(z) do { size_t z0 = ip; while (ip < n && src[ip] == 0) ip++; (z) = ip - z0; if ((z) > ((~(size_t)0) / 255 - 2)) return -1; } while (0)
+  if (src[ip] >= 22) {
+    size_t len = (size_t)src[ip++] - 17;
+    LZO_IN(len);
+    LZO_OUT(len);
+    memcpy(dst + op, src + ip, len);
+    ip += len;
+    op += len;
+    state = 4;
+  } else if (src[ip] >= 18) {
+    nstate = (size_t)src[ip++] - 17;
+    state = nstate;
+    LZO_IN(nstate);
+    LZO_OUT(nstate);
+    memcpy(dst + op, src + ip, nstate);
+    ip += nstate;
+    op += nstate;
+  }
+  for (;;) {
+    LZO_IN(1);
+    const uint8_t inst = src[ip++];
+    if (inst & 0xC0) {
+      LZO_IN(1);
+      lbdist = ((size_t)src[ip++] << 3) + ((inst >> 2) & 7) + 1;
+      lblen = (size_t)(inst >> 5) + 1;
+      nstate = inst & 3;
+    } else if (inst & 0x20) {
+      lblen = (size_t)(inst & 0x1f) + 2;
+      if (lblen == 2) {
+        size_t z;
+        LZO_ZEROS(z);
+        LZO_IN(1);
+        lblen += z * 255 + 31 + src[ip++];
+      }
+      LZO_IN(2);
+      nstate = (size_t)src[ip] | ((size_t)src[ip + 1] << 8);
+      ip += 2;
+      lbdist = (nstate >> 2) + 1;
+      nstate &= 3;
+    } else if (inst & 0x10) {
+      lblen = (size_t)(inst & 7) + 2;
+      if (lblen == 2) {
+        size_t z;
+        LZO_ZEROS(z);
+        LZO_IN(1);
+        lblen += z * 255 + 7 + src[ip++];
+      }
+      LZO_IN(2);
+      nstate = (size_t)src[ip] | ((size_t)src[ip + 1] << 8);
+      ip += 2;
+      lbdist = (((size_t)inst & 8) << 11) + (nstate >> 2);
+      nstate &= 3;
+      if (lbdist == 0) break; /* stream finished */
+      lbdist += 16384;
+    } else if (state == 0) {
+      size_t len = (size_t)inst + 3;
+      if (len == 3) {
+        size_t z;
+        LZO_ZEROS(z);
+        LZO_IN(1);
+        len += z * 255 + 15 + src[ip++];
+      }
+      LZO_IN(len);
+      LZO_OUT(len);
+      memcpy(dst + op, src + ip, len);
+      ip += len;
+      op += len;
+      state = 4;
+      continue;
+    } else if (state != 4) {
+      LZO_IN(1);
+      nstate = inst & 3;
+      lbdist = (size_t)(inst >> 2) + ((size_t)src[ip++] << 2) + 1;
+      lblen = 2;
+    } else {
+      LZO_IN(1);
+      nstate = inst & 3;
+      lbdist = (size_t)(inst >> 2) + ((size_t)src[ip++] << 2) + 2049;
+      lblen = 3;
+    }
+    if (lbdist > op) return -1; /* look-behind before the start of the output */
+    LZO_IN(nstate);
+    LZO_OUT(lblen + nstate);
+    for (size_t i = 0; i < lblen; i++, op++) dst[op] = dst[op - lbdist];
+    state = nstate;
+    memcpy(dst + op, src + ip, nstate);
+    ip += nstate;
+    op += nstate;
+  }
+#undef LZO_IN
+#undef LZO_OUT
+#undef LZO_ZEROS
+  if (lblen != 3) return -1; /* the terminating M4 has length 3 */
+  if (ip != n) return -1;    /* input not consumed / overrun */
+  return (long)op;
+}
+
+/* ------------------------------------------------------------------------------------------
  * RFC 8878 Zstandard frame (no dictionary; content checksum skipped, not verified)
  * ---------------------------------------------------------------------------------------- */
 typedef struct {

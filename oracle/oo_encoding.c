@@ -36,6 +36,7 @@ static long codec_block(int kind, const uint8_t* src, size_t n, uint8_t* dst, si
     case OO_COMP_ZLIB: return oo_inflate_raw(src, n, dst, cap);
     case OO_COMP_SNAPPY: return oo_snappy_raw(src, n, dst, cap);
     case OO_COMP_LZ4: return oo_lz4_block(src, n, dst, cap);
+    case OO_COMP_LZO: return oo_lzo1x(src, n, dst, cap);
     case OO_COMP_ZSTD: return oo_zstd_frame(src, n, dst, cap);
     default: return -1;
   }

@@ -49,6 +49,7 @@ enum { OO_COMP_NONE = 0, OO_COMP_ZLIB = 1, OO_COMP_SNAPPY = 2, OO_COMP_LZO = 3, 
 long oo_inflate_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
 long oo_snappy_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
 long oo_lz4_block(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+long oo_lzo1x(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);     /* LZO1X, as lzokay_native::decompress_all (compression.rs:174-183) */
 long oo_zstd_frame(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
 
 /* compression.rs:113-123 : returns length, *is_original set */

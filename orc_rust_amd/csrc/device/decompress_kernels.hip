@@ -9,6 +9,7 @@
 //   Zstandard     zstd_entropy.h (one wavefront per block: FSE / Huffman) -> lz_exec.h (one workgroup per chunk: the copies)
 //   Snappy, LZ4   lz_parse.h (one workgroup per chunk: the tokens)          -> lz_exec.h
 //   DEFLATE       inflate_device.h: one wavefront per chunk, Huffman decode and copies through an LDS ring (this file)
+//   LZO           lzo_device.h: one wavefront per chunk, through the same LDS ring
 #pragma once
 #include "rle_parse.h"
 
@@ -213,6 +214,7 @@ __device__ __forceinline__ void lzin_literal(LzIn& in, LzOut& o, uint32_t pos, u
 #include "lz_parse.h"
 #include "lz_exec.h"
 #include "inflate_parse.h"
+#include "lzo_device.h"
 
 // DEFLATE chunks: one wavefront each ("original" chunks ride along when no other launch has taken them: copy_too).
 // (`only_deferred`: the chunks inflate_parse_kernel / lz_exec_kernel left alone -- diag == LZX_DEFERRED; this decoder is the authority on
@@ -245,6 +247,25 @@ extern "C" __global__ void __launch_bounds__(64) decompress_deflate_kernel(Chunk
   if (lane == 0) {
     chunks[c].out_len = bad ? 0 : out_len;
     chunks[c].status = bad ? ORC_E_CODEC : 0;
+  }
+}
+
+// LZO1X chunks: one wavefront each (compression.rs:174-183).
+extern "C" __global__ void __launch_bounds__(64) decompress_lzo_kernel(ChunkDesc* chunks, uint32_t n_chunks) {
+  __shared__ __attribute__((aligned(16))) LzStore<65536> lz;  // (an M4 match reaches 48 KiB back)
+  const uint32_t c = blockIdx.x;
+  if (c >= n_chunks) return;
+  const uint32_t lane = threadIdx.x;
+  ChunkDesc d = chunks[c];
+  if (d.kind != 3) return;
+  d.src = as_global(d.src);
+  d.dst = (uint8_t*)as_global((void*)d.dst);
+  uint32_t out_len = 0;
+  const int bad = lzo_wave(d.src, d.src_len, d.dst, d.dst_cap, lane, &out_len, lz_view(lz));
+  if (lane == 0) {
+    chunks[c].out_len = bad ? 0 : out_len;
+    chunks[c].status = bad ? ORC_E_CODEC : 0;
+    chunks[c].diag = (uint32_t)bad;
   }
 }
 

@@ -30,7 +30,7 @@ BASIC = [
     "alltypes.none.orc", "alltypes.snappy.orc", "alltypes.zlib.orc", "alltypes.zstd.orc", "alltypes.lz4.orc",
     "long_bool.orc", "long_bool_gzip.orc", "string_dict.orc", "string_dict_gzip.orc", "string_long.orc",
     "string_long_long.orc", "string_long_long_gzip.orc", "test.orc", "test_bigint.orc", "patched_int.orc",
-    "pyorc_rlev2_patchedbase.orc", "pyarrow_timestamps.orc", "overflowing_timestamps.orc", "demo-12-zlib.orc",
+    "pyorc_rlev2_patchedbase.orc", "pyarrow_timestamps.orc", "overflowing_timestamps.orc", "demo-12-zlib.orc", "alltypes.lzo.orc",
 ]
 BIG = {"demo-12-zlib", "demo-11-zlib"}
 INTEGRATION = [
@@ -38,7 +38,7 @@ INTEGRATION = [
     "TestOrcFile.testPredicatePushdown.orc", "TestOrcFile.testMemoryManagementV11.orc", "TestOrcFile.testMemoryManagementV12.orc",
     "TestOrcFile.testStripeLevelStats.orc", "TestOrcFile.testStringAndBinaryStatistics.orc", "TestOrcFile.testSeek.orc",
     "TestOrcFile.test1.orc", "TestOrcFile.testDate1900.orc", "TestStringDictionary.testRowIndex.orc",
-    "TestVectorOrcFile.testLz4.orc", "TestVectorOrcFile.testZstd.0.12.orc", "decimal.orc",
+    "TestVectorOrcFile.testLz4.orc", "TestVectorOrcFile.testLzo.orc", "TestVectorOrcFile.testZstd.0.12.orc", "decimal.orc",
     "nulls-at-end-snappy.orc", "orc_index_int_string.orc", "orc_split_elim_new.orc",
     "orc_split_elim_cpp.orc", "over1k_bloom.orc", "bloom_filter.orc", "demo-11-zlib.orc",
     "TestOrcFile.testSargSkipPickupGroupWithoutIndexCPlusPlus.orc", "TestOrcFile.testSargSkipPickupGroupWithoutIndexJava.orc",

@@ -51,7 +51,7 @@ def lib():
     global _lib
     if _lib is None:
         L = C.CDLL(build())
-        for name in ("oo_inflate_raw", "oo_snappy_raw", "oo_lz4_block", "oo_zstd_frame"):
+        for name in ("oo_inflate_raw", "oo_snappy_raw", "oo_lz4_block", "oo_zstd_frame", "oo_lzo1x"):
             f = getattr(L, name)
             f.restype = C.c_long
             f.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -92,7 +92,7 @@ def lib():
 
 def codec(name, data, cap):
     out = np.zeros(max(cap, 1), dtype=np.uint8)
-    n = getattr(lib(), {"zlib": "oo_inflate_raw", "snappy": "oo_snappy_raw", "lz4": "oo_lz4_block", "zstd": "oo_zstd_frame"}[name])(
+    n = getattr(lib(), {"zlib": "oo_inflate_raw", "snappy": "oo_snappy_raw", "lz4": "oo_lz4_block", "zstd": "oo_zstd_frame", "lzo": "oo_lzo1x"}[name])(
         bytes(data), len(data), out.ctypes.data, cap)
     if n < 0:
         return None

@@ -277,3 +277,102 @@ def test_malformed_lz4_is_rejected_like_the_oracle(case):
     res = G.gpu_decode(64, [c], [(1, DATA, stream)], compression="lz4", block_size=4096)
     assert res.status()[0] != 0
     G.assert_column_parity(res, 0, c, [(1, DATA, stream)], 64, 8192, compression="lz4", block_size=4096, what=case)
+
+
+# ---- LZO1X (compression.rs:174-183) -------------------------------------------------------------------------
+def lzo_shapes(seed):
+    rng = np.random.default_rng(seed)
+    rnd = lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    words = [b"AIR", b"FOB", b"MAIL", b"RAIL", b"REG AIR", b"SHIP", b"TRUCK", b"DELIVER IN PERSON", b"NONE", b"TAKE BACK RETURN"]
+    far = rnd(20000)
+    far2 = rnd(40000)
+    out = {
+        "zeros": bytes(200000),                                                  # distance-1 overlapping copies, very long matches
+        "period7": (b"abcdefg" * 30000)[:200000],
+        "random": rnd(100000),                                                   # literal runs only
+        "random+zeros": rnd(30000) + bytes(20000) + rnd(3000) + bytes(70000),    # long literal runs between matches
+        "text": b" ".join(words[i] for i in rng.integers(0, len(words), 20000)),  # short literals and copies, small distances (M2)
+        "far20k": far + rnd(500) + far + rnd(700) + far,                         # M4 distances
+        "far40k": far2 + rnd(100) + far2,                                        # ... near the 48 KiB limit
+        "short": b"orc",
+    }
+    return {k: v + bytes((-len(v)) % 8) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("block", [262144, 65536, 1000])
+@pytest.mark.parametrize("m2", [True, False])
+def test_lzo_streams_of_the_test_encoder(block, m2):
+    import lzo_enc
+    for name, raw in lzo_shapes(block).items():
+        c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+        stream = frame(raw, lambda b: lzo_enc.compress(b, use_m2=m2), block)
+        n = len(raw) // 8
+        res = G.gpu_decode(n, [c], [(1, DATA, stream)], compression="lzo", block_size=block)
+        assert res.status()[0] == 0, (name, block, res.status())
+        got = b"".join(bytes(res.batch(b, 0)["values"]) for b in range(res.n_batches))
+        assert got == raw, (name, block)
+        G.assert_column_parity(res, 0, c, [(1, DATA, stream)], n, 8192, compression="lzo", block_size=block, what=("lzo", name, block))
+        res.free()
+
+
+def lzo_chunk(block):
+    h = len(block) << 1
+    return np.frombuffer(bytes([h & 0xFF, (h >> 8) & 0xFF, (h >> 16) & 0xFF]) + block, dtype=np.uint8).copy()
+
+
+def test_lzo_state_dependent_short_matches():
+    import lzo_enc
+    rng = np.random.default_rng(5)
+    lits = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))
+    s = bytearray(lzo_enc._literal_run(lits))
+    s += bytes([(1 << 2) | 2, 3]) + b"XY"      # after a literal run: 3 bytes from 1 + 12 + 2049 back, then 2 literals
+    s += bytes([(2 << 2) | 1, 1]) + b"Z"       # after 2 literals: 2 bytes from 2 + 4 + 1 back, then 1 literal
+    s += bytes([(0 << 2) | 0, 0])              # after 1 literal: 2 bytes from 1 back
+    s += b"\x11\x00\x00"
+    want = bytearray(lits)
+    want += want[len(want) - 2062:len(want) - 2062 + 3] + b"XY"
+    want += want[len(want) - 7:len(want) - 7 + 2] + b"Z"
+    want += want[len(want) - 1:len(want)] * 2
+    want += bytes((-len(want)) % 8)
+    # (pad the plain text to whole doubles with a second chunk of zeros)
+    pad = len(want) - (len(lits) + 3 + 2 + 2 + 1 + 2)
+    stream = np.concatenate([lzo_chunk(bytes(s)), lzo_chunk(lzo_enc.compress(bytes(pad)))]) if pad else lzo_chunk(bytes(s))
+    c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+    n = len(want) // 8
+    res = G.gpu_decode(n, [c], [(1, DATA, stream)], compression="lzo", block_size=8192)
+    assert res.status()[0] == 0, res.status()
+    assert b"".join(bytes(res.batch(b, 0)["values"]) for b in range(res.n_batches)) == bytes(want)
+    G.assert_column_parity(res, 0, c, [(1, DATA, stream)], n, 8192, compression="lzo", block_size=8192, what="lzo short matches")
+
+
+@pytest.mark.parametrize("case", ["no_end_marker", "input_left_over", "lookbehind", "truncated_length", "too_short", "cut_literals",
+                                  "flip0", "flip1", "flip2", "flip3", "flip4", "flip5"])
+def test_malformed_lzo_is_rejected_like_the_oracle(case):
+    import lzo_enc
+    data = (bytes(range(64)) * 40 + b"tail of the block ....")[:2560]
+    good = lzo_enc.compress(data)
+    if case == "no_end_marker":
+        block = good[:-3]
+    elif case == "input_left_over":
+        block = good + b"\x00\x00"
+    elif case == "lookbehind":
+        block = b"\x16abcde" + b"\x20\x40\x00" + b"\x11\x00\x00"
+    elif case == "truncated_length":
+        block = b"\x16abcde" + b"\x20\x00\x00\x00"
+    elif case == "too_short":
+        block = b"\x11\x00"
+    elif case == "cut_literals":
+        block = good[:len(good) // 2]
+    else:
+        rng = np.random.default_rng(int(case[4:]))
+        b = bytearray(good)
+        for _ in range(3):
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        block = bytes(b)
+    c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+    stream = lzo_chunk(block)
+    res = G.gpu_decode(320, [c], [(1, DATA, stream)], compression="lzo", block_size=4096)
+    # (a flipped bit may leave a stream that still decodes: then the bytes must agree; else the error kind)
+    G.assert_column_parity(res, 0, c, [(1, DATA, stream)], 320, 8192, compression="lzo", block_size=4096, what=case)
+    if not case.startswith("flip"):
+        assert res.status()[0] != 0

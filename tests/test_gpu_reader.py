@@ -28,7 +28,7 @@ def flat_names(path):
     return [n for n, c, t in f.flat_columns()], f
 
 
-FILES = ["test.orc", "alltypes.none.orc", "alltypes.snappy.orc", "alltypes.zlib.orc", "alltypes.zstd.orc", "alltypes.lz4.orc",
+FILES = ["test.orc", "alltypes.none.orc", "alltypes.snappy.orc", "alltypes.zlib.orc", "alltypes.zstd.orc", "alltypes.lz4.orc", "alltypes.lzo.orc", "TestVectorOrcFile.testLzo.orc",
          "string_long_long.orc", "string_dict_gzip.orc", "long_bool_gzip.orc", "patched_int.orc", "test_bigint.orc",
          "TestOrcFile.testSnappy.orc", "TestOrcFile.testWithoutIndex.orc", "TestVectorOrcFile.testLz4.orc",
          "TestVectorOrcFile.testZstd.0.12.orc", "decimal.orc", "nulls-at-end-snappy.orc", "TestOrcFile.testSeek.orc",

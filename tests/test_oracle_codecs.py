@@ -82,3 +82,35 @@ def test_chunked_stream_framing():
     assert st == O.OK and out == payload
     st, out = O.stream_decompress(payload, "none")
     assert st == O.OK and out == payload
+
+
+def test_lzo1x_round_trips_and_rejections():
+    """LZO1X (compression.rs:174-183).  No LZO library in the image: the oracle's decoder is pinned at file level by the
+    reference's two LZO fixtures (test_oracle_files.py); here it must undo tests/lzo_enc.py (every instruction form) and
+    reject what lzokay rejects."""
+    import lzo_enc
+    for data in corpora():
+        for m2 in (True, False):
+            comp = lzo_enc.compress(data, use_m2=m2)
+            assert O.codec("lzo", comp, len(data) + 16) == data, (len(data), m2)
+    data = b"abcabcabcabcabcabcabcabcabcabc" * 50
+    comp = lzo_enc.compress(data)
+    assert O.codec("lzo", comp[:-3], len(data) + 16) is None          # no end marker
+    assert O.codec("lzo", comp + b"\x00", len(data) + 16) is None      # input left over
+    assert O.codec("lzo", comp, len(data) - 1) is None                 # output overrun
+    assert O.codec("lzo", b"\x11\x00", 16) is None                     # shorter than the end marker
+    assert O.codec("lzo", b"\x16abcde" + b"\x20\x40\x00" + b"\x11\x00\x00", 64) is None  # look-behind before the output
+    # the state-dependent short matches: 2 bytes from <= 1 KiB after 1..3 literals, 3 bytes from 2049.. after a literal run
+    rng = np.random.default_rng(5)
+    lits = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))
+    s = bytearray(lzo_enc._literal_run(lits))                          # state 4
+    d = 2049 + 3 * 4 + 1                                               # distance (inst >> 2) + (H << 2) + 2049
+    s += bytes([(1 << 2) | 2, 3])                                      # D = 1, H = 3, S = 2: three bytes from 2062 back, then 2 literals
+    s += b"XY"                                                         # state 2
+    s += bytes([(2 << 2) | 0, 1])                                      # D = 2, H = 1: two bytes from 2 + 4 + 1 = 7 back, S = 0
+    s += b"\x11\x00\x00"
+    want = bytearray(lits)
+    want += want[len(want) - 2062:len(want) - 2062 + 3]
+    want += b"XY"
+    want += want[len(want) - 7:len(want) - 7 + 2]
+    assert d == 2062 and O.codec("lzo", bytes(s), len(want) + 16) == bytes(want)
