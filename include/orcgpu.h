@@ -110,9 +110,10 @@ typedef struct {
 typedef struct {
   uint64_t n_rows;           /* Stripe.number_of_rows                                              */
   int32_t compression;       /* ORCGPU_COMP_* (Compression::from_proto, src/compression.rs:52-83)  */
-  uint64_t block_size;       /* max_decompressed_block_size, 0 = 262144 (compression.rs:31).  Every chunk
-                              * must decompress to at most this many bytes (what ORC writers guarantee and
-                              * lz4_flex enforces, compression.rs:185-195); a larger one is ORCGPU_BUILD_DECODER */
+  uint64_t block_size;       /* max_decompressed_block_size, 0 = 262144 (compression.rs:31).  What a chunk of a conforming writer
+                              * expands to at most, and what lz4_flex enforces (compression.rs:185-195).  flate2, lzokay and the
+                              * zstd crate grow their output instead: a chunk of theirs that does not fit is decoded again with
+                              * room for max(block_size, 4 MiB), beyond which it is ORCGPU_BUILD_DECODER */
   int64_t ts_base_seconds;   /* ORC epoch in the writer timezone (array_decoder/timestamp.rs:133-147); 0 = 1420070400 */
   uint32_t batch_size;       /* rows per RecordBatch, 0 = 8192 (arrow_reader.rs:37)                */
   uint32_t n_streams;

@@ -507,6 +507,8 @@ struct PlainStream {
   bool exists = false;
 };
 
+constexpr int ORCGPU_RETRY_LARGER_SLOTS = 1000;  // internal: decode_lane asks for a second run (never leaves the library)
+
 struct DecompStream {
   const orcgpu_staged* stripe;
   const StagedStream* st;

@@ -118,23 +118,3 @@ def make_case(seed, corrupt, hits=1, wide=False, rows=None):
                 data_[int(rng2.integers(0, len(data_)))] = int(rng2.integers(0, 256))
                 streams[sj] = (cid_, kind_, data_)
     return n, comp, block, batch, cols, streams, ((streams[si][0], streams[si][1]) if corrupt and streams else None)
-
-
-def inflates_past_block(streams, comp, block):
-    """Documented divergence: a zlib chunk that inflates to more than the compression block size is
-    rejected by the GPU path; flate2 (read_to_end) and the oracle accept it.  Only corrupted input gets there."""
-    if comp != "zlib":
-        return False
-    import oracle_lib as O
-    for _, _, s in streams:
-        s = bytes(np.asarray(s, dtype=np.uint8).tobytes())
-        pos = 0
-        while pos + 3 <= len(s):
-            h = s[pos] | s[pos + 1] << 8 | s[pos + 2] << 16
-            ln = h >> 1
-            if not (h & 1):
-                r = O.codec("zlib", np.frombuffer(s[pos + 3:pos + 3 + ln], dtype=np.uint8), 1 << 22)
-                if r is not None and len(r) > block:
-                    return True
-            pos += 3 + ln
-    return False

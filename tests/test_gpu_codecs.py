@@ -376,3 +376,41 @@ def test_malformed_lzo_is_rejected_like_the_oracle(case):
     G.assert_column_parity(res, 0, c, [(1, DATA, stream)], 320, 8192, compression="lzo", block_size=4096, what=case)
     if not case.startswith("flip"):
         assert res.status()[0] != 0
+
+
+@pytest.mark.parametrize("kind", ["zlib", "lzo"])
+def test_a_chunk_may_expand_past_the_compression_block_size(kind):
+    """flate2 and lzokay grow their output (compression.rs:142-150, :174-183): a chunk that expands to more than the file's
+    compression block size decodes -- no conforming writer emits one, but the reference reads it.  Here such a chunk first
+    fails in its block-sized slot, gets the head-room the oracle gives the crates (max(block size, 4 MiB)) and the call
+    runs again: same bytes as the oracle; beyond that head-room both reject it."""
+    import lzo_enc
+    comp = CODECS["zlib"] if kind == "zlib" else lzo_enc.compress
+    raw = bytes(range(256)) * 64 + bytes(40000)  # 56 384 bytes in ONE chunk of a file whose block size says 4096
+    block = comp(raw)
+    c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+    stream = lzo_chunk(block)
+    n = len(raw) // 8
+    res = G.gpu_decode(n, [c], [(1, DATA, stream)], compression=kind, block_size=4096)
+    assert res.status()[0] == 0, res.status()
+    assert b"".join(bytes(res.batch(b, 0)["values"]) for b in range(res.n_batches)) == raw
+    G.assert_column_parity(res, 0, c, [(1, DATA, stream)], n, 8192, compression=kind, block_size=4096, what=("oversize", kind))
+    res.free()
+    # ... next to ordinary chunks of the same stream, and a second column that needs no second run
+    raw2 = bytes(range(200)) * 40
+    stream2 = np.concatenate([frame(raw2, comp, 4096), lzo_chunk(block), frame(raw2, comp, 4096)])
+    n2 = (2 * len(raw2) + len(raw)) // 8
+    cols = [c, {"column_id": 2, "orc_type": DOUBLE, "encoding": 0}]
+    streams = [(1, DATA, stream2), (2, DATA, frame(bytes(n2 * 8), comp, 4096))]
+    res = G.gpu_decode(n2, cols, streams, compression=kind, block_size=4096)
+    assert res.status()[0] == 0, res.status()
+    for ci, cc in enumerate(cols):
+        G.assert_column_parity(res, ci, cc, streams, n2, 8192, compression=kind, block_size=4096, what=("oversize in a stream", kind, ci))
+    res.free()
+    # more than 4 MiB out of one chunk: rejected by both
+    big = comp(bytes(5 << 20))
+    stream3 = lzo_chunk(big)
+    res = G.gpu_decode(1000, [c], [(1, DATA, stream3)], compression=kind, block_size=4096)
+    assert res.status()[0] == 9
+    G.assert_column_parity(res, 0, c, [(1, DATA, stream3)], 1000, 8192, compression=kind, block_size=4096, what=("beyond the head-room", kind))
+    res.free()
