@@ -105,6 +105,10 @@ typedef struct {
   uint32_t precision, scale; /* DECIMAL                                      */
   int32_t arrow_target;      /* ORCGPU_ARROW_*                               */
   uint32_t arrow_precision, arrow_scale; /* ORCGPU_ARROW_DECIMAL128           */
+  uint32_t parent;           /* 0: a root column; else 1 + the index in `columns` of the STRUCT this column is a field of
+                              * (Column::children, column.rs; parents come before their children).  A STRUCT column is
+                              * given with orc_type ORCGPU_T_STRUCT: it decodes to a validity bitmap, and its fields' validity
+                              * is theirs merged with it (array_decoder/struct_decoder.rs:58-78, mod.rs:216-252) */
 } orcgpu_column;
 
 typedef struct {

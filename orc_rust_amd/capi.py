@@ -41,7 +41,7 @@ class Stream(C.Structure):
 class Column(C.Structure):
     _fields_ = [("column_id", C.c_uint32), ("orc_type", C.c_int32), ("encoding", C.c_int32), ("dictionary_size", C.c_uint32),
                 ("precision", C.c_uint32), ("scale", C.c_uint32), ("arrow_target", C.c_int32), ("arrow_precision", C.c_uint32),
-                ("arrow_scale", C.c_uint32)]
+                ("arrow_scale", C.c_uint32), ("parent", C.c_uint32)]
 
 
 class StripeDesc(C.Structure):
@@ -219,6 +219,7 @@ class Context:
             carr[i].arrow_target = c.get("arrow_target", 0)
             carr[i].arrow_precision = c.get("arrow_precision", 0)
             carr[i].arrow_scale = c.get("arrow_scale", 0)
+            carr[i].parent = c.get("parent", 0)  # 1 + index of the Struct column this one is a field of (0: a root column)
         d = StripeDesc(n_rows, COMP[compression] if isinstance(compression, str) else compression, block_size, ts_base, batch_size,
                        len(streams), sarr, len(columns), carr, writer_timezone.encode() if writer_timezone else None)
         out = C.c_void_p()

@@ -29,24 +29,53 @@ struct PresJob {
   unsigned long long* null_counts; // per batch
   uint64_t* nonnull_out;           // scalar: non-null rows of the column
   uint64_t* ceil8_out;             // BOOLEAN columns: ceil(nonnull / 8) (bytes of the DATA job), else null
-  const RleJob* job;               // the PRESENT byte-RLE job (its error word says where decoding stopped)
+  const RleJob* job;               // the PRESENT byte-RLE job (its error word says where decoding stopped); null: the column has no PRESENT stream of its own
   uint64_t n_rows, n_words, n_rank_tiles, n_out_words;
   uint32_t batch, words_per_batch;
+  // a child of a Struct: its PRESENT stream has one bit per row in which the PARENT is present (array_decoder/mod.rs:216-252,
+  // merge_parent_present); the column's validity over the stripe's rows is those bits dealt out to the parent's set bits
+  const unsigned long long* parent_vbits;  // the parent's stripe-wide validity words (null: a root column)
+  const uint32_t* parent_rank;             // ... and the non-null rows before each of them
+  uint64_t* ceil8b_out;            // Struct columns: ceil(nonnull / 8) = bytes of their children's PRESENT streams, else null
 };
 
 __device__ __forceinline__ void present_word(const PresJob& j, uint64_t w) {
-  uint64_t x = ld_u64(j.pbytes + w * 8);
-  // reverse the bits inside each byte: bitreverse64 reverses everything, bswap restores byte order
-  unsigned long long v = __builtin_bswap64(__builtin_bitreverse64(x));
-  const unsigned long long e = j.job->err;
-  if (e != RLE_NO_ERR) {
-    const uint64_t bits = (e >> 8) * 8;
-    if (bits < j.n_rows) {
-      const uint64_t cutoff = bits / j.batch * j.batch;  // first row of the batch that fails
-      if (w * 64 + 64 > cutoff) v |= w * 64 >= cutoff ? ~0ull : ~0ull << (cutoff - w * 64);
+  unsigned long long v;
+  uint64_t rows_here = j.n_rows - w * 64;
+  if (!j.parent_vbits) {
+    uint64_t x = ld_u64(j.pbytes + w * 8);
+    // reverse the bits inside each byte: bitreverse64 reverses everything, bswap restores byte order
+    v = __builtin_bswap64(__builtin_bitreverse64(x));
+    const unsigned long long e = j.job->err;
+    if (e != RLE_NO_ERR) {
+      const uint64_t bits = (e >> 8) * 8;
+      if (bits < j.n_rows) {
+        const uint64_t cutoff = bits / j.batch * j.batch;  // first row of the batch that fails
+        if (w * 64 + 64 > cutoff) v |= w * 64 >= cutoff ? ~0ull : ~0ull << (cutoff - w * 64);
+      }
+    }
+  } else {
+    const unsigned long long pv = j.parent_vbits[w];
+    if (!j.pbytes) {
+      v = pv;  // no PRESENT stream of its own: null exactly where the parent is (derive_present_vec: (None, Some(parent)))
+    } else {
+      // the column's bits for this word: popcount(pv) of them, from bit parent_rank[w] of its own stream on
+      const uint64_t r = j.parent_rank[w];
+      const uint64_t a = __builtin_bswap64(__builtin_bitreverse64(ld_u64(j.pbytes + (r >> 3))));
+      const uint64_t b = __builtin_bswap64(__builtin_bitreverse64(ld_u64(j.pbytes + (r >> 3) + 8)));  // (slack behind the stream)
+      const uint32_t sh = (uint32_t)(r & 7);
+      unsigned long long c = sh ? (a >> sh) | (b << (64 - sh)) : a;
+      const unsigned long long e = j.job->err;
+      if (e != RLE_NO_ERR) {  // (the stream failed to decode: the bits it did not deliver read as present, like a root column's)
+        const uint64_t bits = (e >> 8) * 8;
+        if (bits < r + 64) c |= bits <= r ? ~0ull : ~0ull << (bits - r);
+      }
+      // deal them out to the set bits of the parent's word, lowest first
+      v = 0;
+      for (unsigned long long m = pv; m; m &= m - 1, c >>= 1)
+        if (c & 1) v |= m & (0 - m);
     }
   }
-  uint64_t rows_here = j.n_rows - w * 64;
   if (rows_here < 64) v &= (1ull << rows_here) - 1;
   j.vbits[w] = v;
   j.wpop[w] = (uint32_t)__builtin_popcountll(v);
@@ -113,6 +142,7 @@ extern "C" __global__ void __launch_bounds__(256) pres_scan_sums_kernel(const Pr
   if (threadIdx.x == 0) {
     *j.nonnull_out = carry_s;
     if (j.ceil8_out) *j.ceil8_out = (carry_s + 7) / 8;
+    if (j.ceil8b_out) *j.ceil8b_out = (carry_s + 7) / 8;
   }
 }
 extern "C" __global__ void __launch_bounds__(256) pres_scan_apply_kernel(const PresJob* jobs) {

@@ -19,6 +19,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -305,6 +306,8 @@ struct ColumnOut {
   uint32_t column_id = 0;
   uint32_t width = 0;        // fixed width in bytes (0 for strings / boolean)
   bool is_string = false, is_bool = false;
+  bool is_struct = false;    // validity only; its fields are the columns whose `parent` names it
+  int32_t parent = -1;       // index in orcgpu_result::cols of the Struct this column is a field of
   int32_t ts_unit = 3;
   uint32_t precision = 0, scale = 0;
   bool has_present = false;
@@ -372,6 +375,7 @@ struct orcgpu_result {
   int full_status = 0;           // status of the underlying decode (before the selection re-mapped the failing batch)
   uint32_t full_err_batch = 0, full_err_col = 0;
   std::vector<ColumnOut> cols;
+  std::vector<std::string> field_names;  // per column: the name of a Struct's field (set by the file reader; empty: "f<position>")
   int status = 0;
   uint32_t err_batch = 0, err_col = 0;
   uint64_t arrow_bytes = 0;
@@ -479,7 +483,9 @@ uint32_t type_width(int t) {
 bool is_string_type(int t) { return t == ORCGPU_T_STRING || t == ORCGPU_T_VARCHAR || t == ORCGPU_T_CHAR || t == ORCGPU_T_BINARY; }
 
 // ---- per-call plan ------------------------------------------------------------------------------
-enum JobClass { JC_PRESENT = 0, JC_RLE2 = 1, JC_RLE1 = 2, JC_BYTE = 3, JC_COUNT = 4 };
+// (JC_PRESENT1..3: PRESENT streams of the fields of Structs, by depth: they are as long as their parent has non-null rows)
+enum JobClass { JC_PRESENT = 0, JC_RLE2 = 1, JC_RLE1 = 2, JC_BYTE = 3, JC_PRESENT1 = 4, JC_PRESENT2 = 5, JC_PRESENT3 = 6, JC_COUNT = 7 };
+constexpr int kMaxStructDepth = 3;
 
 struct JobPlan {
   int cls;
@@ -520,7 +526,11 @@ struct ColPlan {
   int stripe, col;
   orcgpu_column c;
   uint64_t n_rows;
-  bool has_present = false;
+  bool has_present = false;   // the column has validity: a PRESENT stream of its own, or a Struct above it has
+  bool own_present = false;   // ... of its own
+  int parent_plan = -1;       // index in Plan::cols of the Struct this column is a field of (only when that one has validity)
+  int depth = 0;              // Structs above it
+  uint32_t ceil8_idx = 0;     // Struct: scalar holding ceil(non-null rows / 8), the length of its fields' PRESENT streams
   bool tz = false;            // TIMESTAMP of a stripe with a writer time zone: re-labelled to UTC, which can yield nulls
   PlainStream present, data, length, secondary, dict;
   // scratch

@@ -1,0 +1,109 @@
+"""Struct columns on the device (array_decoder/struct_decoder.rs:58-78; parent / child PRESENT merge, mod.rs:216-252): a field's
+PRESENT stream has one bit per row in which the Struct is present; the field's Arrow validity is those bits dealt out to the
+Struct's valid rows.  Files are read through the reader front end (Arrow C Data export builds the nested arrays) and compared
+with PyArrow (= Apache ORC C++, the oracle the reference's integration suite is pinned to): the reference's nested_struct.orc,
+and files the ORC C++ writer makes here from tables with nulls at every level."""
+import numpy as np
+import pyarrow as pa
+import pyarrow.orc as orc
+import pytest
+
+import arrow_util as A
+from orc_rust_amd import ArrowReaderBuilder, capi
+
+pytestmark = pytest.mark.gpu
+_ctx = None
+
+
+def ctx():
+    global _ctx
+    if _ctx is None:
+        _ctx = capi.Context(0)
+    return _ctx
+
+
+def read_all(path, names=None, batch_size=8192, prefetch=2, selection=None):
+    b = ArrowReaderBuilder.try_new(path, ctx()).with_batch_size(batch_size).with_prefetch(prefetch)
+    if names is not None:
+        b = b.with_projection(names)
+    if selection is not None:
+        b = b.with_row_selection(selection)
+    return list(b.build())
+
+
+def table_of(batches):
+    """the batches as one table (a root column is `not null` in batches without nulls -- RecordBatch::try_from_iter -- so the
+    batch schemas differ in that flag: the columns are put together, not the batches)"""
+    names = batches[0].schema.names
+    return pa.table({n: pa.chunked_array([b.column(i) for b in batches]) for i, n in enumerate(names)})
+
+
+def test_the_references_nested_struct_file():
+    path = A.data_path("nested_struct.orc")
+    want = A.expected_table("nested_struct")
+    batches = read_all(path)
+    got = table_of(batches)
+    assert got.schema.names == ["nest"] and got.schema.field("nest").type == want.schema.field("nest").type
+    assert got.column("nest").to_pylist() == want.column("nest").to_pylist()
+    assert got.column("nest").to_pylist() == [{"a": 1.0, "b": True}, {"a": 3.0, "b": None}, {"a": None, "b": None}, None, {"a": -3.0, "b": None}]
+
+
+def struct_table(n, seed):
+    rng = np.random.default_rng(seed)
+    def maybe(vals, p):
+        mask = rng.random(n) < p
+        return pa.array(vals, mask=mask)
+    inner = pa.StructArray.from_arrays(
+        [maybe(rng.normal(size=n), 0.2), maybe(rng.random(n) < 0.5, 0.3), maybe(rng.integers(-1000, 1000, n).astype(np.int16), 0.0)],
+        names=["d", "e", "h"], mask=pa.array(rng.random(n) < 0.15))
+    words = np.array(["", "AIR", "REG AIR", "TRUCK", "a much longer string value than the others", "ü–€"])
+    outer = pa.StructArray.from_arrays(
+        [maybe(rng.integers(-2**40, 2**40, n), 0.1), maybe(words[rng.integers(0, len(words), n)], 0.25), inner,
+         maybe(rng.integers(0, 3650, n).astype("datetime64[D]"), 0.5)],
+        names=["a", "b", "c", "g"], mask=pa.array(rng.random(n) < 0.3))
+    all_there = pa.StructArray.from_arrays([pa.array(rng.integers(0, 100, n)), maybe(rng.random(n), 0.4)], names=["x", "y"])  # a Struct without PRESENT
+    return pa.table({"id": pa.array(np.arange(n)), "s": outer, "t": all_there, "plain": maybe(rng.integers(0, 9, n).astype(np.int32), 0.05)})
+
+
+@pytest.mark.parametrize("compression", ["zstd", "uncompressed", "zlib"])
+@pytest.mark.parametrize("batch_size", [8192, 1000])
+def test_structs_with_nulls_at_every_level(tmp_path, compression, batch_size):
+    n = 60_000
+    t = struct_table(n, 11)
+    path = str(tmp_path / "structs.orc")
+    orc.write_table(t, path, compression=compression, stripe_size=1 << 16)
+    f = orc.ORCFile(path)
+    assert f.nstripes >= 2
+    want = f.read()
+    for prefetch in (0, 2):
+        batches = read_all(path, batch_size=batch_size, prefetch=prefetch)
+        assert all(b.num_rows <= batch_size for b in batches)
+        got = table_of(batches)
+        assert got.schema.names == want.schema.names
+        for name in want.schema.names:
+            g, w = got.column(name).combine_chunks(), want.column(name).combine_chunks()
+            assert g.type == w.type, (name, g.type, w.type)
+            assert g.equals(w), name
+    # a projection that leaves the Structs out, and one that takes only a Struct
+    assert table_of(read_all(path, ["plain", "id"])).column("plain").combine_chunks().equals(want.column("plain").combine_chunks())
+    only = table_of(read_all(path, ["s"]))
+    assert only.schema.names == ["s"] and only.column("s").combine_chunks().equals(want.column("s").combine_chunks())
+
+
+def test_row_selection_over_struct_columns(tmp_path):
+    n = 30_000
+    t = struct_table(n, 5)
+    path = str(tmp_path / "structs.orc")
+    orc.write_table(t, path, compression="zstd", stripe_size=1 << 16)
+    want = orc.ORCFile(path).read()
+    sel = [(100, True), (5000, False), (9000, True), (3, False), (12000, True), (3000, False), (897, True)]  # (all 30 000 rows: stripes behind a selection's end are read whole, arrow_reader.rs:296-308)
+    got = table_of(read_all(path, batch_size=777, selection=sel))
+    keep = np.zeros(n, dtype=bool)
+    at = 0
+    for cnt, skip in sel:
+        if not skip:
+            keep[at:at + cnt] = True
+        at += cnt
+    exp = want.filter(pa.array(keep))
+    for name in want.schema.names:
+        assert got.column(name).combine_chunks().equals(exp.column(name).combine_chunks()), name
