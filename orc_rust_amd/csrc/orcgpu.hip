@@ -307,6 +307,11 @@ struct ColumnOut {
   uint32_t width = 0;        // fixed width in bytes (0 for strings / boolean)
   bool is_string = false, is_bool = false;
   bool is_struct = false;    // validity only; its fields are the columns whose `parent` names it
+  bool is_list = false;      // List / Map: per-batch int32 offsets restarting at 0 (list.rs:63-87, map.rs:74-104); char_total / char_base count
+                             // ELEMENTS; the elements themselves are the columns of orcgpu_result::subs[sub]
+  bool is_map = false;
+  int32_t sub = -1;
+  bool elem = false;         // below a List / Map: decoded as a column of that one's sub-result, nothing of it lives in this result
   int32_t parent = -1;       // index in orcgpu_result::cols of the Struct this column is a field of
   int32_t ts_unit = 3;
   uint32_t precision = 0, scale = 0;
@@ -376,6 +381,10 @@ struct orcgpu_result {
   uint32_t full_err_batch = 0, full_err_col = 0;
   std::vector<ColumnOut> cols;
   std::vector<std::string> field_names;  // per column: the name of a Struct's field (set by the file reader; empty: "f<position>")
+  // Elements of the List / Map columns: one result each over a "stripe" whose rows are the column's elements (all of the
+  // stripe's, ONE batch), whose root columns are the element column(s) -- a Map's key and value -- with everything below them
+  std::vector<orcgpu_result*> subs;
+  std::vector<uint32_t> src_col;         // sub-results: per column, its index in the columns of the staged stripe
   int status = 0;
   uint32_t err_batch = 0, err_col = 0;
   uint64_t arrow_bytes = 0;

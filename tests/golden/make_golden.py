@@ -30,7 +30,7 @@ BASIC = [
     "alltypes.none.orc", "alltypes.snappy.orc", "alltypes.zlib.orc", "alltypes.zstd.orc", "alltypes.lz4.orc",
     "long_bool.orc", "long_bool_gzip.orc", "string_dict.orc", "string_dict_gzip.orc", "string_long.orc",
     "string_long_long.orc", "string_long_long_gzip.orc", "test.orc", "test_bigint.orc", "patched_int.orc",
-    "pyorc_rlev2_patchedbase.orc", "pyarrow_timestamps.orc", "overflowing_timestamps.orc", "demo-12-zlib.orc", "alltypes.lzo.orc", "nested_struct.orc",
+    "pyorc_rlev2_patchedbase.orc", "pyarrow_timestamps.orc", "overflowing_timestamps.orc", "demo-12-zlib.orc", "alltypes.lzo.orc", "nested_struct.orc", "nested_array.orc", "nested_map.orc", "nested_array_float.orc", "nested_array_struct.orc", "nested_map_struct.orc",
 ]
 BIG = {"demo-12-zlib", "demo-11-zlib"}
 INTEGRATION = [
