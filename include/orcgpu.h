@@ -94,6 +94,14 @@ typedef struct {
   int32_t kind;        /* ORCGPU_S_* */
   const uint8_t* ptr;  /* HOST pointer (pageable or pinned) */
   uint64_t len;
+  /* Entry point (0, 0: the stream is given from its start).  A stream may be given from a row group on: `ptr` then starts at
+   * the chunk header (compressed file) or at the byte (uncompressed file) a ROW_INDEX position names, and the decoder of the
+   * stream starts `skip_bytes` into the (decompressed) bytes and drops the first `skip_values` values it decodes there -- the
+   * three numbers a RowIndexEntry holds per stream (row_index.rs:42-50; orcgpu_index_entry splits an entry's positions by
+   * stream).  Dictionary streams (DICTIONARY_DATA, the LENGTH stream of a dictionary) are always given whole.  The bytes may
+   * reach beyond what the rows need: what lies behind the values the stripe's rows consume is not looked at. */
+  uint32_t skip_bytes;
+  uint32_t skip_values; /* PRESENT / Boolean DATA: in bytes of the bit stream (the entry's bit offset must be 0) */
 } orcgpu_stream;
 
 /* One projected leaf column: what Column / DataType / ColumnEncoding carry (src/column.rs:24-59). */
@@ -200,6 +208,23 @@ typedef struct {
  * of a selected batch are used in place, its validity bitmap, Boolean bits and offsets are rebuilt on the device.
  * Selectors are normalised like `From<Vec<RowSelector>>` (row_selection.rs:466-482). */
 int orcgpu_result_select(orcgpu_ctx* ctx, orcgpu_result* r, const orcgpu_row_selector* selectors, uint32_t n);
+/* Host only: one stream's share of a RowIndexEntry's positions (row_index.rs:42-50, :204-226; the reference keeps the list
+ * and never seeks with it).  `positions` is the entry of ONE row group of ONE column as the ROW_INDEX stream holds it;
+ * the streams of the column take their numbers from it in the order PRESENT, DATA, then LENGTH or SECONDARY:
+ * a compressed file gives every stream {offset of a chunk header in the stream, bytes into the decompressed chunk}, an
+ * uncompressed one {byte offset}; run-length streams add {values of the run at that byte already consumed}, bit streams
+ * (PRESENT, Boolean DATA) after that {bits of the current byte consumed}; dictionary streams have no positions.
+ * Describe the column as it is in the stripe: `has_present` = it has a PRESENT stream, `compressed` = the file has a
+ * compression codec.  Returns the numbers for stream `kind`, or ORCGPU_OUT_OF_SPEC when the entry has not exactly the
+ * positions such a column needs (writers that drop an all-ones PRESENT stream drop its positions too). */
+typedef struct {
+  uint64_t chunk_offset;  /* where, in the stream's bytes, the entry's chunk header is (uncompressed: the byte itself) */
+  uint32_t skip_bytes;    /* bytes into the decompressed chunk (uncompressed: 0)                                       */
+  uint32_t skip_values;   /* run-length streams: values (bit streams: bytes) of the run there already consumed          */
+  uint32_t skip_bits;     /* bit streams: bits of that byte consumed                                                   */
+} orcgpu_stream_entry;
+int orcgpu_index_entry(const orcgpu_column* column, int has_present, int compressed, const uint64_t* positions, uint32_t n_positions,
+                       int32_t kind, orcgpu_stream_entry* out);
 /* Host only: the UTC offsets (seconds east of Greenwich) the library uses for a writer time zone at n instants (seconds since
  * the UNIX epoch), and the ORC epoch in that zone (2015-01-01T00:00:00 there, timestamp.rs:133-147; orc_epoch may be NULL).
  * ORCGPU_UNSUPPORTED when the tz database does not have the zone. */
@@ -256,6 +281,16 @@ int orcgpu_reader_set_timestamp_precision(orcgpu_reader* r, int arrow_target);  
 /* with_row_selection (arrow_reader.rs:113): a selection over the rows of the FILE; every stripe takes its share with
  * RowSelection::split_off, and once no rows are left in the selection later stripes are read whole (arrow_reader.rs:296-308). */
 int orcgpu_reader_set_row_selection(orcgpu_reader* r, const orcgpu_row_selector* selectors, uint32_t n);
+/* Row groups under a row selection (default: on).  The reference decodes a stripe from its first row and discards what a
+ * selection skips (skip_values, rle_v2/mod.rs:148-175).  This reader reads the stripe's ROW_INDEX streams (row_index.rs:204-226)
+ * and reads, stages and decodes only the row groups (rowIndexStride rows, stripe.rs:300) that hold selected rows -- every
+ * stream from the entry point its index names, consecutive row groups together; a stripe without selected rows is not read
+ * at all.  The batches are the ones the whole decode yields.  Stripes without usable indexes (no ROW_INDEX streams, an entry
+ * that does not fit its column, bit streams entered in mid-byte, List / Map columns) are decoded whole.  What differs, on
+ * damaged files only: an error inside row groups that are not read is not met.  `on` = 0 turns it off. */
+int orcgpu_reader_set_row_group_pruning(orcgpu_reader* r, int on);
+/* How many row groups the reader has read and how many the stripes it went through hold (whole stripes count all of theirs). */
+int orcgpu_reader_row_groups(const orcgpu_reader* r, uint64_t* read, uint64_t* total);
 /* Read-ahead: how many decoded stripes the reader may be ahead of the caller (default 4, at most 8; 0 = none: every stripe is
  * read, staged, decoded and copied back inside the orcgpu_reader_next_batch call that needs it).  With read-ahead two threads
  * of the reader work beside the caller: one reads and stages the stripes to come, one decodes the stripes staged so far

@@ -71,6 +71,12 @@ class ArrowReaderBuilder:
         self._ctx._check(self._ctx.L.orcgpu_reader_set_row_selection(self._h, capi.selector_array(selectors), len(selectors)))
         return self
 
+    def with_row_group_pruning(self, on):
+        """Under a row selection, read only the row groups that hold selected rows (orcgpu_reader_set_row_group_pruning;
+        default on).  The batches are the same either way."""
+        self._ctx._check(self._ctx.L.orcgpu_reader_set_row_group_pruning(self._h, 1 if on else 0))
+        return self
+
     def with_prefetch(self, stripes):
         """Read-ahead of the reader (orcgpu_reader_set_prefetch): decoded stripes it may be ahead of the consumer; 0 = none.
         The counterpart of choosing ArrowStreamReader (async_arrow_reader.rs) over ArrowReader: the batches are the same."""
@@ -99,6 +105,12 @@ class ArrowReader:
 
     def total_row_count(self):
         return self._ctx.L.orcgpu_reader_total_rows(self._h)
+
+    def row_groups(self):
+        """(row groups read so far, row groups of the stripes gone through so far): orcgpu_reader_row_groups."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._ctx._check(self._ctx.L.orcgpu_reader_row_groups(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def column_names(self):
         n = self._ctx.L.orcgpu_reader_column_count(self._h)

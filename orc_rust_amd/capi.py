@@ -23,6 +23,7 @@ EXPORTS = [
     "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_fetch_async", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_timezone_offsets", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
     "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
     "orcgpu_reader_set_projection", "orcgpu_reader_set_projection_roots", "orcgpu_reader_set_schema", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection", "orcgpu_reader_set_prefetch",
+    "orcgpu_reader_set_row_group_pruning", "orcgpu_reader_row_groups", "orcgpu_index_entry",
     "orcgpu_reader_total_rows", "orcgpu_reader_stripe_count", "orcgpu_reader_column_count", "orcgpu_reader_column_name",
     "orcgpu_reader_next_batch",
 ]
@@ -35,7 +36,12 @@ class OrcGpuError(RuntimeError):
 
 
 class Stream(C.Structure):
-    _fields_ = [("column_id", C.c_uint32), ("kind", C.c_int32), ("ptr", C.c_void_p), ("len", C.c_uint64)]
+    _fields_ = [("column_id", C.c_uint32), ("kind", C.c_int32), ("ptr", C.c_void_p), ("len", C.c_uint64),
+                ("skip_bytes", C.c_uint32), ("skip_values", C.c_uint32)]
+
+
+class StreamEntry(C.Structure):
+    _fields_ = [("chunk_offset", C.c_uint64), ("skip_bytes", C.c_uint32), ("skip_values", C.c_uint32), ("skip_bits", C.c_uint32)]
 
 
 class Column(C.Structure):
@@ -139,6 +145,9 @@ def load():
     L.orcgpu_result_fetch.argtypes = [C.c_void_p, C.c_void_p]
     L.orcgpu_result_fetch_async.argtypes = [C.c_void_p, C.c_void_p]
     L.orcgpu_reader_set_prefetch.argtypes = [C.c_void_p, C.c_uint32]
+    L.orcgpu_reader_set_row_group_pruning.argtypes = [C.c_void_p, C.c_int]
+    L.orcgpu_reader_row_groups.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.orcgpu_index_entry.argtypes = [C.POINTER(Column), C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_uint32, C.c_int32, C.POINTER(StreamEntry)]
     L.orcgpu_result_select.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RowSelector), C.c_uint32]
     L.orcgpu_selection_batches.argtypes = [C.POINTER(RowSelector), C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                            C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(RowSelector), C.c_uint32, C.POINTER(C.c_uint32)]
@@ -196,12 +205,15 @@ class Context:
             raise OrcGpuError(rc, self.error())
 
     def stage(self, n_rows, streams, columns, compression="none", block_size=262144, batch_size=8192, ts_base=0, writer_timezone=None):
-        """streams: [(column_id, kind, bytes)], columns: [dict(column_id, orc_type, encoding, dictionary_size, precision, scale, arrow_target)]"""
-        keep = [bytes(b) if not isinstance(b, (bytes, np.ndarray)) else b for _, _, b in streams]
+        """streams: [(column_id, kind, bytes)] or [(column_id, kind, bytes, skip_bytes, skip_values)] (entry points), columns: [dict(column_id, orc_type, encoding, dictionary_size, precision, scale, arrow_target)]"""
+        keep = [bytes(s[2]) if not isinstance(s[2], (bytes, np.ndarray)) else s[2] for s in streams]
         sarr = (Stream * max(1, len(streams)))()
-        for i, ((cid, kind, _), buf) in enumerate(zip(streams, keep)):
+        for i, (s, buf) in enumerate(zip(streams, keep)):
+            cid, kind = s[0], s[1]
             sarr[i].column_id = cid
             sarr[i].kind = kind
+            if len(s) > 3:
+                sarr[i].skip_bytes, sarr[i].skip_values = s[3], s[4]
             if isinstance(buf, np.ndarray):
                 sarr[i].ptr = buf.ctypes.data
                 sarr[i].len = buf.nbytes

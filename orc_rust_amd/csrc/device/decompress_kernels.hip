@@ -34,7 +34,8 @@ struct StreamDesc {
   uint32_t err_idx;     // scalar receiving a codec error flag
   uint8_t* base;        // start of the stream's plain buffer
   uint32_t framing_error;
-  uint32_t pad;
+  uint32_t skip;        // a stream entered at a row group: bytes of its first chunk that belong to the rows before (the plain length
+                        // published is what lies behind them; the consumers start there)
 };
 
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
@@ -297,7 +298,7 @@ extern "C" __global__ void __launch_bounds__(256) decompress_finalize_kernel(con
     total += c.out_len;
   }
   if (threadIdx.x == 0) {
-    scalars[s.len_idx] = total;
+    scalars[s.len_idx] = total > s.skip ? total - s.skip : 0;
     if (err) scalars[s.err_idx] = err;
   }
 }

@@ -154,7 +154,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
   const uint8_t* data = as_global(j->data);
   void* out = as_global(j->out);
   const uint64_t len = scalars[j->len_idx];
-  const uint64_t needed = scalars[j->needed_idx];
+  const uint64_t needed = scalars[j->needed_idx] + j->skip;
   const bool is_signed = j->is_signed;
   constexpr int nbits = NB;       // the reference's NInt width: the Arrow value width, but for dictionary keys (64-bit decoder, 32-bit keys)
   constexpr bool narrow = NB != OB * 8;

@@ -28,6 +28,9 @@ struct RleJob {
   uint32_t first_bad;      // first block whose entry disagrees with its predecessor (verify round)
   uint32_t stat_bad;       // verify round: number of inconsistent blocks (diagnostics)
   uint32_t stat_repaired;  // repair kernel: blocks rewritten (diagnostics)
+  uint32_t skip;           // a stream entered at a row group (orcgpu_stream::skip_values): values of its first run that belong to
+                           // the rows before; they are decoded in front of the column's values (the consumers start behind them)
+  uint32_t pad;
   unsigned long long err;  // min over (first value index of the failing run << 8 | ORC_E_*)
   unsigned long long err_pos;  // min over (stream position of the failing run << 8 | ORC_E_*): its code is the first failure's
 };

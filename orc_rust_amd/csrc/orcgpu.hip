@@ -132,6 +132,7 @@ struct StagedStream {
   uint64_t len;
   std::vector<ChunkInfo> chunks;  // only for compressed stripes
   std::vector<ZChunkParse> zchunks;  // Zstandard: frame / block headers of every compressed chunk
+  uint32_t skip_bytes = 0, skip_values = 0;  // entry point (orcgpu_stream): where in the plain bytes the decoder starts, values it drops
   bool framing_error = false;     // truncated chunk header / payload (compression.rs:253-261 panics)
   uint64_t framed_len = 0;        // bytes covered by well-formed chunks
 };
@@ -291,6 +292,9 @@ struct orcgpu_staged {
   hipEvent_t ready = nullptr;  // recorded on the copy stream behind the stripe's last piece
   std::shared_ptr<orcgpu_ctx::Zone> zone;  // writer time zone of the stripe (null: none given)
   uint64_t stream_bytes = 0;
+  // the file reader's row selection on these rows, as the batches it yields (rows counted from the first row staged)
+  bool has_sel = false;
+  std::vector<SelBatch> sel;
   const StagedStream* find(uint32_t col, int kind) const {
     for (auto& s : streams)
       if (s.column_id == col && s.kind == kind) return &s;
@@ -509,6 +513,7 @@ struct JobPlan {
   uint64_t expect_values;   // host estimate of values (for group sizing)
   // filled while laying out
   uint32_t block0 = 0, nblocks = 0, group0 = 0, ngroups = 0, group_size = 64;
+  uint32_t skip_values = 0;            // of the stream's entry point: decoded in front of the output (RleJob::skip)
   int stripe = 0, col = 0, role = 0;  // role: stream kind the job decodes
   int final_index = -1;
 };
@@ -519,6 +524,7 @@ struct PlainStream {
   uint64_t len_upper = 0;
   uint32_t len_idx = 0;          // scalar holding the actual plain length
   uint32_t err_idx = 0;          // scalar holding a codec error flag (compressed streams)
+  uint32_t skip_values = 0;      // entered at a row group: values of the first run that come before the column's (orcgpu_stream)
   bool exists = false;
 };
 
@@ -720,6 +726,23 @@ int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_sta
       s->desc.ts_base_seconds = s->zone->epoch;
     }
   }
+  for (uint32_t i = 0; i < d->n_streams; i++) {
+    // entry points (orcgpu_stream): a run holds at most 512 values, a chunk at most block_size bytes; dictionaries come whole
+    const orcgpu_stream& in = d->streams[i];
+    if (!in.skip_bytes && !in.skip_values) continue;
+    bool dict_stream = in.kind == ORCGPU_S_DICTIONARY_DATA;
+    for (uint32_t k = 0; k < d->n_columns; k++)
+      if (d->columns[k].column_id == in.column_id && in.kind == ORCGPU_S_LENGTH && is_string_type(d->columns[k].orc_type) &&
+          d->columns[k].orc_type != ORCGPU_T_BINARY &&
+          (d->columns[k].encoding == ORCGPU_ENC_DICTIONARY || d->columns[k].encoding == ORCGPU_ENC_DICTIONARY_V2))
+        dict_stream = true;
+    if (in.skip_values > 512 || in.skip_bytes > s->desc.block_size || dict_stream) {
+      set_err(ctx, "stream (column %u, kind %d): entry point {%u bytes, %u values} is not one a ROW_INDEX position can name", in.column_id, in.kind,
+              in.skip_bytes, in.skip_values);
+      delete s;
+      return ORCGPU_INVALID_ARGUMENT;
+    }
+  }
   s->cols.assign(d->columns, d->columns + d->n_columns);
   s->desc.columns = nullptr;
   s->desc.streams = nullptr;
@@ -730,6 +753,8 @@ int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_sta
     st.column_id = in.column_id;
     st.kind = in.kind;
     st.len = in.len;
+    st.skip_bytes = in.skip_bytes;
+    st.skip_values = in.skip_values;
     st.off = b.take(in.len + ORC_PAD);
     s->stream_bytes += in.len;
     if (d->compression != ORCGPU_COMP_NONE) scan_chunks(in.ptr, in.len, d->compression, s->desc.block_size, st);
@@ -879,10 +904,12 @@ PlainStream plan_stream(Plan& P, orcgpu_staged* s, uint32_t col, int kind) {
     return ps;
   }
   ps.exists = true;
+  ps.skip_values = st->skip_values;
   if (s->desc.compression == ORCGPU_COMP_NONE) {
-    ps.dev = s->dev + st->off;
-    ps.len_upper = st->len;
-    ps.len_idx = P.new_scalar(st->len);
+    const uint64_t skip = std::min<uint64_t>(st->skip_bytes, st->len);
+    ps.dev = s->dev + st->off + skip;
+    ps.len_upper = st->len - skip;
+    ps.len_idx = P.new_scalar(st->len - skip);
   } else {
     uint64_t upper = 0;
     for (auto& c : st->chunks) upper += c.plain_cap;
@@ -891,6 +918,10 @@ PlainStream plan_stream(Plan& P, orcgpu_staged* s, uint32_t col, int kind) {
     ps.len_idx = P.new_scalar(0);  // written by the decompress finalize kernel
     ps.err_idx = P.new_scalar(0);
     P.decomp.push_back(DecompStream{s, st, ps.scratch_off, ps.len_idx, ps.err_idx});
+    // (the decoders start behind the bytes of the rows before the entry point; the finalize kernel publishes what is left)
+    const uint64_t skip = std::min<uint64_t>(st->skip_bytes, upper);
+    ps.scratch_off += skip;
+    ps.len_upper -= skip;
   }
   return ps;
 }
@@ -909,7 +940,8 @@ int add_job(Plan& P, int cls, uint8_t codec, bool is_signed, uint8_t nbits, uint
   j.len_idx = ps.len_idx;
   j.needed_idx = needed_idx;
   j.total_idx = P.new_scalar(0);
-  j.expect_values = expect_values;
+  j.expect_values = expect_values + ps.skip_values;
+  j.skip_values = ps.skip_values;
   j.stripe = stripe;
   j.col = col;
   j.role = role;

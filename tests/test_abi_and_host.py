@@ -52,6 +52,45 @@ def test_product_never_imports_the_oracle():
                 assert "oracle_lib" not in text and "liborc_oracle" not in text and "orc_oracle.h" not in text, f
 
 
+def test_row_index_positions_are_dealt_out_by_stream():
+    """orcgpu_index_entry (host only): one RowIndexEntry's positions (row_index.rs:42-50) split over the column's streams in the
+    order PRESENT, DATA, LENGTH | SECONDARY, with the forms the ORC specification gives each stream kind."""
+    import ctypes as C
+    from orc_rust_amd import capi
+    L = capi.load()
+
+    def entry(orc_type, encoding, has_present, compressed, positions, kind):
+        col = capi.Column()
+        col.orc_type, col.encoding = orc_type, encoding
+        pos = (C.c_uint64 * max(1, len(positions)))(*positions)
+        out = capi.StreamEntry()
+        rc = L.orcgpu_index_entry(C.byref(col), int(has_present), int(compressed), pos, len(positions), kind, C.byref(out))
+        return rc, (out.chunk_offset, out.skip_bytes, out.skip_values, out.skip_bits)
+
+    PRESENT, DATA, LENGTH, SECONDARY = 0, 1, 2, 5
+    LONG, STRING, BOOLEAN, DOUBLE, DECIMAL, TIMESTAMP, STRUCT = 4, 7, 0, 6, 14, 9, 12
+    # Long, compressed, with PRESENT: 4 + 3 positions
+    p = [100, 7, 3, 0, 2000, 11, 5]
+    assert entry(LONG, 2, True, True, p, PRESENT) == (0, (100, 7, 3, 0))
+    assert entry(LONG, 2, True, True, p, DATA) == (0, (2000, 11, 5, 0))
+    assert entry(LONG, 2, True, True, p[:6], DATA)[0] == 2       # OutOfSpec: one position short
+    assert entry(LONG, 2, False, True, p, DATA)[0] == 2          # ... four too many for a column without PRESENT
+    # uncompressed: {byte, run offset}
+    assert entry(LONG, 2, False, False, [4096, 17], DATA) == (0, (4096, 0, 17, 0))
+    # direct string: DATA = bytes only, LENGTH = run-length; dictionary string: DATA = run-length keys, nothing for LENGTH
+    assert entry(STRING, 2, False, True, [10, 20, 30, 40, 50], DATA) == (0, (10, 20, 0, 0))
+    assert entry(STRING, 2, False, True, [10, 20, 30, 40, 50], LENGTH) == (0, (30, 40, 50, 0))
+    assert entry(STRING, 3, False, True, [10, 20, 30], DATA) == (0, (10, 20, 30, 0))
+    assert entry(STRING, 3, False, True, [10, 20, 30], LENGTH)[0] == 101  # InvalidArgument: the dictionary's lengths have no positions
+    # Boolean: bits over byte runs; Double: bytes; Decimal: bytes + scales; Timestamp: two run-length streams; Struct: PRESENT only
+    assert entry(BOOLEAN, 0, False, False, [9, 2, 5], DATA) == (0, (9, 0, 2, 5))
+    assert entry(DOUBLE, 0, True, False, [1, 0, 0, 800], DATA) == (0, (800, 0, 0, 0))
+    assert entry(DECIMAL, 2, False, True, [1, 2, 3, 4, 5], SECONDARY) == (0, (3, 4, 5, 0))
+    assert entry(TIMESTAMP, 2, False, False, [1, 2, 3, 4], SECONDARY) == (0, (3, 0, 4, 0))
+    assert entry(STRUCT, 0, True, True, [1, 2, 3, 4], PRESENT) == (0, (1, 2, 3, 4))
+    assert entry(STRUCT, 0, False, True, [], PRESENT)[0] == 101
+
+
 def test_sharding_helpers():
     from orc_rust_amd import shard
     assert shard.stripe_shard(12, 1, 8) == [1, 9]
