@@ -152,11 +152,14 @@ def build_workload(args, rank, world):
             n = min(C2_STRIPE_ROWS, rows - s * C2_STRIPE_ROWS)
             kind = {"c2": "direct" if s % 2 == 0 else "delta", "c2-direct": "direct", "c2-delta": "delta", "c2-arange": "arange", "c2-adv": "adv", "c2-rowgroup": "rg"}[wl]
             if s in mine:
-                stripes.append(W.c2_adversarial_stripe(n, s)[:4] if kind == "adv" else (W.c2_rowgroup_stripe(n, s)[:4] if kind == "rg" else W.c2_stripe(n, s, kind, row0=s * C2_STRIPE_ROWS)[:4]))
+                idx = not args.no_row_index  # the DATA stream's ROW_INDEX positions go with it (verified run starts for the walk)
+                stripes.append(W.c2_adversarial_stripe(n, s, index=idx)[:4] if kind == "adv" else (W.c2_rowgroup_stripe(n, s, index=idx)[:4] if kind == "rg" else W.c2_stripe(n, s, kind, row0=s * C2_STRIPE_ROWS)[:4]))
         label = "C2%s: RLEv2 Int64 column, %d rows, uncompressed, %d stripes" % (
             " (DIRECT 48-bit / DELTA 8-bit alternating)" if wl == "c2" else (
                 " DIRECT 48-bit with the encoder flushed every 10 000 rows (row-group boundaries of a real writer)" if wl == "c2-rowgroup" else " adversarial walk (run lengths 200..511, widths 3..58 bits changing per run, every third run PATCHED_BASE)" if wl == "c2-adv" else " variant " + wl[3:]),
             rows, n_stripes)
+        if wl in ("c2-adv", "c2-rowgroup"):
+            label += ", the stream's ROW_INDEX positions (one per 10 000 rows) " + ("withheld" if args.no_row_index else "given as verified run starts")
     elif wl == "c3":
         comp = args.compression or "snappy"
         for s in mine:
@@ -416,6 +419,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-row-index", action="store_true",
+                    help="c2-adv / c2-rowgroup: stage the stream without its ROW_INDEX positions (a file written without indexes)")
     ap.add_argument("--workload", default="lineitem", choices=["lineitem", "c2", "c2-direct", "c2-delta", "c2-arange", "c2-adv", "c2-rowgroup", "c3", "c5"],
                     help="lineitem (default) = the headline; the others are BASELINE.md's remaining configs, recorded under profiles/")
     ap.add_argument("--compression", default=None, choices=[None, "none", "zstd", "snappy", "lz4", "zlib"])

@@ -89,6 +89,15 @@ typedef struct {
 } orcgpu_opts;
 
 /* One entry of Stripe.stream_map (src/stripe.rs:311-316): raw, possibly compressed bytes. */
+/* Where a row group starts in a stream: what a RowIndexEntry holds for it (row_index.rs:42-50; orcgpu_index_entry below deals
+ * an entry's positions out to the column's streams). */
+typedef struct {
+  uint64_t chunk_offset;  /* where, in the stream's bytes, the entry's chunk header is (uncompressed file: the byte itself) */
+  uint32_t skip_bytes;    /* bytes into the decompressed chunk (uncompressed: 0)                                         */
+  uint32_t skip_values;   /* run-length streams: values (bit streams: bytes) of the run there already consumed            */
+  uint32_t skip_bits;     /* bit streams: bits of that byte consumed                                                     */
+} orcgpu_stream_entry;
+
 typedef struct {
   uint32_t column_id;
   int32_t kind;        /* ORCGPU_S_* */
@@ -102,6 +111,13 @@ typedef struct {
    * reach beyond what the rows need: what lies behind the values the stripe's rows consume is not looked at. */
   uint32_t skip_bytes;
   uint32_t skip_values; /* PRESENT / Boolean DATA: in bytes of the bit stream (the entry's bit offset must be 0) */
+  /* Optional (NULL, 0: none): where the stripe's later row groups start in this stream, in stream order, chunk_offset counted
+   * from `ptr` -- the ROW_INDEX positions of the stream.  Run-length streams use them as verified run starts: one lane per
+   * row group follows the run headers from its entry to the next (some tens of dependent steps instead of the whole stream's),
+   * which gives every 512-byte block of the stream its first header without the search the decoder otherwise makes for
+   * them.  Only a hint: entries that do not lie on the stream's run chain are noticed and ignored. */
+  const orcgpu_stream_entry* entries;
+  uint32_t n_entries;
 } orcgpu_stream;
 
 /* One projected leaf column: what Column / DataType / ColumnEncoding carry (src/column.rs:24-59). */
@@ -217,12 +233,6 @@ int orcgpu_result_select(orcgpu_ctx* ctx, orcgpu_result* r, const orcgpu_row_sel
  * Describe the column as it is in the stripe: `has_present` = it has a PRESENT stream, `compressed` = the file has a
  * compression codec.  Returns the numbers for stream `kind`, or ORCGPU_OUT_OF_SPEC when the entry has not exactly the
  * positions such a column needs (writers that drop an all-ones PRESENT stream drop its positions too). */
-typedef struct {
-  uint64_t chunk_offset;  /* where, in the stream's bytes, the entry's chunk header is (uncompressed: the byte itself) */
-  uint32_t skip_bytes;    /* bytes into the decompressed chunk (uncompressed: 0)                                       */
-  uint32_t skip_values;   /* run-length streams: values (bit streams: bytes) of the run there already consumed          */
-  uint32_t skip_bits;     /* bit streams: bits of that byte consumed                                                   */
-} orcgpu_stream_entry;
 int orcgpu_index_entry(const orcgpu_column* column, int has_present, int compressed, const uint64_t* positions, uint32_t n_positions,
                        int32_t kind, orcgpu_stream_entry* out);
 /* Host only: the UTC offsets (seconds east of Greenwich) the library uses for a writer time zone at n instants (seconds since

@@ -35,13 +35,13 @@ class OrcGpuError(RuntimeError):
         self.code = code
 
 
-class Stream(C.Structure):
-    _fields_ = [("column_id", C.c_uint32), ("kind", C.c_int32), ("ptr", C.c_void_p), ("len", C.c_uint64),
-                ("skip_bytes", C.c_uint32), ("skip_values", C.c_uint32)]
-
-
 class StreamEntry(C.Structure):
     _fields_ = [("chunk_offset", C.c_uint64), ("skip_bytes", C.c_uint32), ("skip_values", C.c_uint32), ("skip_bits", C.c_uint32)]
+
+
+class Stream(C.Structure):
+    _fields_ = [("column_id", C.c_uint32), ("kind", C.c_int32), ("ptr", C.c_void_p), ("len", C.c_uint64),
+                ("skip_bytes", C.c_uint32), ("skip_values", C.c_uint32), ("entries", C.c_void_p), ("n_entries", C.c_uint32)]
 
 
 class Column(C.Structure):
@@ -205,7 +205,8 @@ class Context:
             raise OrcGpuError(rc, self.error())
 
     def stage(self, n_rows, streams, columns, compression="none", block_size=262144, batch_size=8192, ts_base=0, writer_timezone=None):
-        """streams: [(column_id, kind, bytes)] or [(column_id, kind, bytes, skip_bytes, skip_values)] (entry points), columns: [dict(column_id, orc_type, encoding, dictionary_size, precision, scale, arrow_target)]"""
+        """streams: [(column_id, kind, bytes)] or [(column_id, kind, bytes, skip_bytes, skip_values)] (entry points; a sixth element: the positions of the later row groups as an array [groups, 2] = (byte, values) for an
+        uncompressed or [groups, 3] = (chunk header offset, bytes into the chunk, values) for a compressed stream), columns: [dict(column_id, orc_type, encoding, dictionary_size, precision, scale, arrow_target)]"""
         keep = [bytes(s[2]) if not isinstance(s[2], (bytes, np.ndarray)) else s[2] for s in streams]
         sarr = (Stream * max(1, len(streams)))()
         for i, (s, buf) in enumerate(zip(streams, keep)):
@@ -214,6 +215,16 @@ class Context:
             sarr[i].kind = kind
             if len(s) > 3:
                 sarr[i].skip_bytes, sarr[i].skip_values = s[3], s[4]
+            if len(s) > 5 and s[5] is not None and len(s[5]):
+                pos = np.asarray(s[5], dtype=np.uint64)
+                earr = (StreamEntry * len(pos))()
+                ev = np.frombuffer(earr, dtype=np.dtype([("o", "<u8"), ("b", "<u4"), ("v", "<u4"), ("t", "<u4"), ("p", "<u4")]))
+                ev["o"] = pos[:, 0]
+                ev["b"] = pos[:, 1] if pos.shape[1] == 3 else 0
+                ev["v"] = pos[:, -1]
+                keep.append(earr)
+                sarr[i].entries = C.addressof(earr)
+                sarr[i].n_entries = len(pos)
             if isinstance(buf, np.ndarray):
                 sarr[i].ptr = buf.ctypes.data
                 sarr[i].len = buf.nbytes

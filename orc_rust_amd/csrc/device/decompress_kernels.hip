@@ -272,12 +272,15 @@ extern "C" __global__ void __launch_bounds__(64) decompress_lzo_kernel(ChunkDesc
 
 // One workgroup per stream: make the plain chunks contiguous (they already are unless a chunk in
 // the middle came out shorter than its slot), publish the plain length, stop at the first bad chunk.
-extern "C" __global__ void __launch_bounds__(256) decompress_finalize_kernel(const ChunkDesc* chunks, const StreamDesc* streams, uint64_t* scalars) {
+// chunk_start (optional): per chunk, where its plain bytes start in the stream (for the verified run starts of rle_hint_kernel)
+extern "C" __global__ void __launch_bounds__(256) decompress_finalize_kernel(const ChunkDesc* chunks, const StreamDesc* streams, uint64_t* scalars,
+                                                                             uint32_t* chunk_start) {
   StreamDesc s = streams[blockIdx.x];
   uint64_t total = 0;
   uint32_t err = s.framing_error ? ORC_E_IO : 0;
   for (uint32_t i = 0; i < s.n_chunks; i++) {
     const ChunkDesc& c = chunks[s.first_chunk + i];
+    if (chunk_start && threadIdx.x == 0) chunk_start[s.first_chunk + i] = (uint32_t)(total > 0xffffffffull ? 0xffffffffull : total);
     if (c.status) {
       err = c.status;
       break;

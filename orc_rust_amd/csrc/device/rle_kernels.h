@@ -31,8 +31,17 @@ struct RleJob {
   uint32_t skip;           // a stream entered at a row group (orcgpu_stream::skip_values): values of its first run that belong to
                            // the rows before; they are decoded in front of the column's values (the consumers start behind them)
   uint32_t pad;
+  // verified run starts (orcgpu_stream::entries): this job's slice of the call's RleHint table; hint_bad is set by
+  // rle_hint_kernel when the entries do not lie on one run chain (they are then ignored)
+  uint32_t hint0, n_hints, hint_bad, hint_skip;
   unsigned long long err;  // min over (first value index of the failing run << 8 | ORC_E_*)
   unsigned long long err_pos;  // min over (stream position of the failing run << 8 | ORC_E_*): its code is the first failure's
+};
+
+// One verified run start: the chunk of the stream it lies in (index within the call's chunk table; ~0: the stream is not
+// compressed) and the byte inside that chunk's plain bytes
+struct RleHint {
+  uint32_t job, chunk, byte, pad;
 };
 
 struct RleBlocks {
@@ -44,4 +53,5 @@ struct RleBlocks {
   uint8_t* flags;       // 1 = strong: entry verified by the candidate search (or filled by a strong owner)
   uint32_t* badmap;     // 1 bit per block: inconsistent at the verify round (zeroed every call)
   uint32_t* group_job;  // per expansion group: class-relative job index (one table per job class, back to back)
+  uint32_t* hint;       // per block: its entry as the verified run starts give it (~0: none); null when no stream of the call has any
 };

@@ -122,6 +122,56 @@ __device__ __forceinline__ void walk_dispatch(const RleJob* j, const uint8_t* da
   else walk_block<CODEC_BYTE>(data, len, lb, entry, false, 8, ex, nv);
 }
 
+// Verified run starts (ROW_INDEX positions, orcgpu_stream::entries): one lane per entry follows the run headers from its
+// position to the next entry's (the stream's end for the last) and notes, for every block a run carries it into, where that
+// block's first header is.  A stream's entries start with its first byte.  Entries that are not in order, or a chain that
+// does not arrive exactly at the next entry, mark the job: the guess round then ignores its hints.
+template <int CODEC>
+__device__ __forceinline__ bool hint_chain(const uint8_t* data, uint64_t len, uint64_t p, uint64_t end, bool is_signed, int nbits, uint32_t* hint) {
+  while (p < end) {
+    uint32_t hsize, hn, herr;
+    hop_parse<CODEC>(data + p, len - p, is_signed, nbits, hsize, hn, herr);
+    if (herr || !hsize) return false;  // (a run that does not parse: the ordinary walk deals with the stream)
+    const uint64_t q = p + hsize;
+    for (uint64_t b = p / RLE_BLK + 1; b <= q / RLE_BLK && b * RLE_BLK < len; b++) hint[b] = (uint32_t)(q - b * RLE_BLK);
+    p = q;
+  }
+  return p == end || end >= len;
+}
+extern "C" __global__ void __launch_bounds__(64) rle_hint_kernel(RleJob* jobs, const RleHint* hints, uint32_t n_hints, RleBlocks blk,
+                                                                  const uint64_t* scalars, const uint32_t* chunk_start) {
+  const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+  if (t >= n_hints) return;
+  const RleHint h = hints[t];
+  RleJob* j = jobs + h.job;
+  const uint64_t len = scalars[j->len_idx];
+  auto position = [&](const RleHint& e) -> int64_t {
+    return (int64_t)(e.chunk == 0xffffffffu ? 0u : chunk_start[e.chunk]) + (int64_t)e.byte - (int64_t)j->hint_skip;
+  };
+  const int64_t p0 = position(h);
+  int64_t p1 = (int64_t)len;
+  if (t + 1 < j->hint0 + j->n_hints) p1 = position(hints[t + 1]);
+  if (p1 > (int64_t)len) p1 = (int64_t)len;
+  if (p0 < 0 || p0 > p1) {
+    atomicOr(&j->hint_bad, 1u);
+    return;
+  }
+  uint32_t* hint = blk.hint + j->block0;
+  if (t == j->hint0) {
+    if (p0 != 0) {
+      atomicOr(&j->hint_bad, 1u);
+      return;
+    }
+    hint[0] = 0;
+  }
+  const uint8_t* data = as_global(j->data);
+  bool ok;
+  if (j->codec == CODEC_RLE2) ok = hint_chain<CODEC_RLE2>(data, len, (uint64_t)p0, (uint64_t)p1, j->is_signed, j->nbits, hint);
+  else if (j->codec == CODEC_RLE1) ok = hint_chain<CODEC_RLE1>(data, len, (uint64_t)p0, (uint64_t)p1, j->is_signed, j->nbits, hint);
+  else ok = hint_chain<CODEC_BYTE>(data, len, (uint64_t)p0, (uint64_t)p1, false, 8, hint);
+  if (!ok) atomicOr(&j->hint_bad, 1u);
+}
+
 // A "full run" header at p that is followed by `hops` more headers of the same kind.
 // `bm` (optional): prefilter bitmaps of the 64 blocks from byte `wbase` on -- a header position whose
 // bit is clear cannot start a full run (rejects without touching memory), and a set bit stands in
@@ -347,8 +397,12 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
     if ((b & 31) == 0) blk.badmap[b >> 5] = 0;  // the verify round marks blocks here
     uint32_t want = 0, strong = 0;
     bool need = false;
+    const uint32_t hinted = live && blk.hint && j->n_hints && !j->hint_bad ? blk.hint[b] : 0xffffffffu;
     if (live) {
       if (lb == 0) {
+        strong = 1;
+      } else if (hinted != 0xffffffffu) {
+        want = hinted;  // the run chain from a verified start gives the block's first header (rle_hint_kernel)
         strong = 1;
       } else {
         // stride guess from the stream's first run: exact for streams of equal-sized runs

@@ -133,6 +133,7 @@ struct StagedStream {
   std::vector<ChunkInfo> chunks;  // only for compressed stripes
   std::vector<ZChunkParse> zchunks;  // Zstandard: frame / block headers of every compressed chunk
   uint32_t skip_bytes = 0, skip_values = 0;  // entry point (orcgpu_stream): where in the plain bytes the decoder starts, values it drops
+  std::vector<std::pair<uint32_t, uint32_t>> hints;  // verified run starts (orcgpu_stream::entries): (chunk index or ~0, byte in its plain bytes), the stream's start first
   bool framing_error = false;     // truncated chunk header / payload (compression.rs:253-261 panics)
   uint64_t framed_len = 0;        // bytes covered by well-formed chunks
 };
@@ -514,6 +515,8 @@ struct JobPlan {
   // filled while laying out
   uint32_t block0 = 0, nblocks = 0, group0 = 0, ngroups = 0, group_size = 64;
   uint32_t skip_values = 0;            // of the stream's entry point: decoded in front of the output (RleJob::skip)
+  const StagedStream* hint_src = nullptr;  // verified run starts, if the stream has any
+  uint32_t chunk0 = 0;
   int stripe = 0, col = 0, role = 0;  // role: stream kind the job decodes
   int final_index = -1;
 };
@@ -525,6 +528,8 @@ struct PlainStream {
   uint32_t len_idx = 0;          // scalar holding the actual plain length
   uint32_t err_idx = 0;          // scalar holding a codec error flag (compressed streams)
   uint32_t skip_values = 0;      // entered at a row group: values of the first run that come before the column's (orcgpu_stream)
+  const StagedStream* src = nullptr;  // (for its verified run starts)
+  uint32_t chunk0 = 0;           // compressed: index of the stream's first chunk in the call's chunk table
   bool exists = false;
 };
 
@@ -587,6 +592,7 @@ struct Plan {
   uint64_t spacejobs_off = 0;          // device copy of the SpaceJob table
   std::vector<SpaceJob> spacejobs;
   std::vector<DictJob> dictjobs;       // host copy, same order as pending_gathers
+  uint32_t decomp_chunks = 0;        // chunks of the streams in `decomp` so far
   std::vector<DecompStream> decomp;  // compressed streams to expand before anything else  // indices into cols: dictionary string columns waiting for their gather
   uint32_t new_scalar(uint64_t v) {
     scalars.push_back(v);
@@ -758,6 +764,30 @@ int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_sta
     st.off = b.take(in.len + ORC_PAD);
     s->stream_bytes += in.len;
     if (d->compression != ORCGPU_COMP_NONE) scan_chunks(in.ptr, in.len, d->compression, s->desc.block_size, st);
+    if (in.entries && in.n_entries && in.n_entries < (1u << 24)) {
+      // verified run starts: the stream's first byte, then the entries (each named by the chunk it lies in: the chunk's place in
+      // the plain stream is only known on the device).  Anything odd drops them all: they are a hint
+      bool ok = true;
+      st.hints.push_back({d->compression == ORCGPU_COMP_NONE ? 0xffffffffu : 0u, st.skip_bytes});
+      size_t ck = 0;
+      for (uint32_t e = 0; e < in.n_entries && ok; e++) {
+        const orcgpu_stream_entry& en = in.entries[e];
+        if (d->compression == ORCGPU_COMP_NONE) {
+          ok = en.chunk_offset + en.skip_bytes <= in.len && en.chunk_offset + en.skip_bytes <= 0xffffffffull;
+          st.hints.push_back({0xffffffffu, (uint32_t)(en.chunk_offset + en.skip_bytes)});
+        } else {
+          while (ck < st.chunks.size() && st.chunks[ck].src_off < en.chunk_offset + 3) ck++;
+          ok = ck < st.chunks.size() && st.chunks[ck].src_off == en.chunk_offset + 3;
+          st.hints.push_back({(uint32_t)ck, en.skip_bytes});
+        }
+        if (ok && st.hints.size() >= 2) {
+          const auto &a = st.hints[st.hints.size() - 2], &b = st.hints.back();
+          ok = a.first < b.first || (a.first == b.first && a.second <= b.second);
+        }
+      }
+      if (!ok) st.hints.clear();
+      else if (st.hints.size() >= 2 && st.hints[0] == st.hints[1]) st.hints.erase(st.hints.begin());
+    }
     s->streams.push_back(std::move(st));
   }
   s->dev_bytes = align_up(b.off + ORC_PAD);
@@ -905,6 +935,7 @@ PlainStream plan_stream(Plan& P, orcgpu_staged* s, uint32_t col, int kind) {
   }
   ps.exists = true;
   ps.skip_values = st->skip_values;
+  ps.src = st;
   if (s->desc.compression == ORCGPU_COMP_NONE) {
     const uint64_t skip = std::min<uint64_t>(st->skip_bytes, st->len);
     ps.dev = s->dev + st->off + skip;
@@ -917,6 +948,8 @@ PlainStream plan_stream(Plan& P, orcgpu_staged* s, uint32_t col, int kind) {
     ps.scratch_off = P.scratch.take(upper + ORC_PAD);
     ps.len_idx = P.new_scalar(0);  // written by the decompress finalize kernel
     ps.err_idx = P.new_scalar(0);
+    ps.chunk0 = P.decomp_chunks;
+    P.decomp_chunks += (uint32_t)st->chunks.size();
     P.decomp.push_back(DecompStream{s, st, ps.scratch_off, ps.len_idx, ps.err_idx});
     // (the decoders start behind the bytes of the rows before the entry point; the finalize kernel publishes what is left)
     const uint64_t skip = std::min<uint64_t>(st->skip_bytes, upper);
@@ -942,6 +975,8 @@ int add_job(Plan& P, int cls, uint8_t codec, bool is_signed, uint8_t nbits, uint
   j.total_idx = P.new_scalar(0);
   j.expect_values = expect_values + ps.skip_values;
   j.skip_values = ps.skip_values;
+  if (ps.src && !ps.src->hints.empty() && ps.len_upper < 0xffffffffull) j.hint_src = ps.src;
+  j.chunk0 = ps.chunk0;
   j.stripe = stripe;
   j.col = col;
   j.role = role;

@@ -44,6 +44,7 @@ def lib():
         pp, ps = C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)
         L.orcgen_rle2.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, pp, ps, C.c_void_p]
         L.orcgen_rle2_segments.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, pp, ps, C.c_void_p]
+        L.orcgen_rle2_indexed.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_void_p, pp, ps]
         L.orcgen_rle1.argtypes = [C.c_void_p, C.c_size_t, C.c_int, pp, ps]
         L.orcgen_byte_rle.argtypes = [C.c_void_p, C.c_size_t, pp, ps]
         L.orcgen_bool.argtypes = [C.c_void_p, C.c_size_t, pp, ps]
@@ -83,6 +84,18 @@ def rle2_segments(values, seg_lens, signed=True, aligned=False, stats=False):
     lib().orcgen_rle2_segments(v.ctypes.data, v.size, sl.ctypes.data, sl.size, int(signed), int(aligned), C.byref(out), C.byref(n), st.ctypes.data)
     buf = _take(out, n)
     return (buf, dict(zip(("short_repeat", "direct", "patched_base", "delta"), st.tolist()))) if stats else buf
+
+
+def rle2_indexed(values, stride, seg_lens=None, signed=True, aligned=False):
+    """RLE v2 (flushed behind every segment when seg_lens is given) and, as a writer records them for its ROW_INDEX stream,
+    the positions of every stride-th value: an array [groups, 2] of (bytes written, values the encoder held) -- the stream's
+    share of the RowIndexEntry of an uncompressed file (row_index.rs:42-50)."""
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    sl = np.ascontiguousarray(seg_lens if seg_lens is not None else [], dtype=np.uint32)
+    pos = np.zeros(((v.size + stride - 1) // stride, 2), dtype=np.uint64)
+    out, n = C.c_void_p(), C.c_size_t()
+    lib().orcgen_rle2_indexed(v.ctypes.data, v.size, sl.ctypes.data, sl.size, int(signed), int(aligned), stride, pos.ctypes.data, C.byref(out), C.byref(n))
+    return _take(out, n), pos
 
 
 def rle1(values, signed=True):

@@ -409,6 +409,38 @@ int orcgen_rle2_segments(const int64_t* vals, size_t n, const uint32_t* seg_lens
   return 0;
 }
 
+/* Public: orcgen_rle2_segments (n_seg = 0: no forced flushes) that also records, as a writer does for its ROW_INDEX streams, the
+ * position of every `stride`-th value: positions[2g] = bytes written when value g * stride arrives, positions[2g + 1] = values
+ * the encoder holds at that moment (they open the run(s) that start at that byte).  ceil(n / stride) pairs. */
+int orcgen_rle2_indexed(const int64_t* vals, size_t n, const uint32_t* seg_lens, size_t n_seg, int is_signed, int aligned, uint32_t stride,
+                        uint64_t* positions, uint8_t** out, size_t* out_len) {
+  obuf b = {0, 0, 0};
+  rle2* e = (rle2*)calloc(1, sizeof(rle2));
+  e->out = &b;
+  e->is_signed = is_signed;
+  e->aligned = aligned;
+  size_t i = 0, k = 0;
+  uint32_t in_seg = 0;
+  for (; i < n; i++) {
+    if (stride && i % stride == 0) {
+      positions[2 * (i / stride)] = b.len;
+      positions[2 * (i / stride) + 1] = (uint64_t)e->n;
+    }
+    rle2_put(e, vals[i]);
+    if (k < n_seg && ++in_seg == seg_lens[k]) {
+      rle2_flush(e);
+      in_seg = 0;
+      k++;
+    }
+  }
+  rle2_flush(e);
+  free(e);
+  ob_reserve(&b, 64);
+  *out = b.p;
+  *out_len = b.len;
+  return 0;
+}
+
 /* RLE v1 (spec: runs of 3..130 with delta -128..127, literal groups up to 128) */
 int orcgen_rle1(const int64_t* vals, size_t n, int is_signed, uint8_t** out, size_t* out_len) {
   obuf b = {0, 0, 0};

@@ -211,15 +211,15 @@ def test_structs_and_unusable_indexes(tmp_path):
 
 def test_reference_fixtures_with_and_without_index():
     """TestOrcFile.testSeek.orc / testWithoutIndex.orc (the reference's fixtures): selections over their flat columns."""
-    import arrow_files as A
+    import arrow_util as A
     for name in ("TestOrcFile.testSeek.orc", "TestOrcFile.testWithoutIndex.orc"):
         path = A.data_path(name)
         f = orc.ORCFile(path)
         flat = [fld.name for fld in f.schema if not pa.types.is_nested(fld.type)]
         total = f.nrows
         sel = [S(1234), K(77), S(total // 2), K(300), S(total - 1234 - 77 - total // 2 - 300)]
-        a, (g_read, g_total) = read(path, flat, sel, True, batch_size=100)
-        b, _ = read(path, flat, sel, False, batch_size=100)
+        a, (g_read, g_total) = read(path, flat, sel, True, batch_size=1000)
+        b, _ = read(path, flat, sel, False, batch_size=1000)
         assert len(a) == len(b) and all(x.equals(y) for x, y in zip(a, b)), name
         assert sum(x.num_rows for x in a) == 377
         if "WithoutIndex" not in name:
@@ -263,3 +263,42 @@ def test_entry_points_at_the_stripe_boundary():
     # an entry point no index can name is refused
     with pytest.raises(capi.OrcGpuError):
         G.gpu_decode(10, cols, [(1, 1, raw, 0, 5000)])
+
+
+def _chunk_positions(comp, plain_positions, block_size):
+    """(byte, values) of the plain stream -> (chunk header offset, bytes into the chunk, values) of the framed one."""
+    raw = bytes(comp)
+    heads, at = [], 0
+    while at < len(raw):
+        heads.append(at)
+        at += 3 + ((raw[at] | (raw[at + 1] << 8) | (raw[at + 2] << 16)) >> 1)
+    return np.array([[heads[int(b) // block_size], int(b) % block_size, int(v)] for b, v in plain_positions], dtype=np.uint64)
+
+
+def test_verified_run_starts():
+    """orcgpu_stream::entries: the ROW_INDEX positions of a run-length stream as verified run starts of the walk.  Streams
+    whose runs change length and width all the time (the walk's worst case without them) and streams flushed at every row
+    group, uncompressed and compressed; entries that do not lie on the run chain are ignored.  The values are the same."""
+    import gpu_util as G
+    from orc_rust_amd import gen
+    from orc_rust_amd.gen import workloads as W
+    for make in (W.c2_adversarial_stripe, W.c2_rowgroup_stripe):
+        n, cols, streams, expect, _ = make(600_000, 3, index=True)
+        plain = [s[:3] for s in streams]
+        res = G.gpu_decode(n, cols, streams)
+        W.check_result(res, cols, expect)
+        G.assert_column_parity(res, 0, cols[0], plain, n, 8192, what=(make.__name__, "entries"))
+        res.free()
+        cid, kind, stream, _, _, pos = streams[0]
+        for comp, block in (("zstd", 65536), ("snappy", 4096), ("zlib", 262144)):
+            framed = gen.compress_stream(stream, comp, block)
+            res = G.gpu_decode(n, cols, [(cid, kind, framed, 0, 0, _chunk_positions(framed, pos, block))], compression=comp, block_size=block)
+            W.check_result(res, cols, expect)
+            res.free()
+        # off the chain (one byte late), out of order, beyond the stream: hints only
+        late = pos.copy()
+        late[:, 0] += 1
+        for bad in (late, pos[::-1].copy(), pos + np.uint64(len(bytes(stream)))):
+            res = G.gpu_decode(n, cols, [(cid, kind, stream, 0, 0, bad)])
+            W.check_result(res, cols, expect)
+            res.free()
