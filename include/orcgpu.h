@@ -301,6 +301,47 @@ int orcgpu_reader_set_row_selection(orcgpu_reader* r, const orcgpu_row_selector*
 int orcgpu_reader_set_row_group_pruning(orcgpu_reader* r, int on);
 /* How many row groups the reader has read and how many the stripes it went through hold (whole stripes count all of theirs). */
 int orcgpu_reader_row_groups(const orcgpu_reader* r, uint64_t* read, uint64_t* total);
+/* ---- predicate pushdown onto row groups (src/predicate.rs, src/row_group_filter.rs, arrow_reader.rs:173, :258-308) ---- */
+/* A Predicate as a list of nodes in pre-order: a node, then its children one after the other (AND / OR: n_children of them,
+ * NOT: one; comparisons and null tests: none). */
+enum { ORCGPU_PRED_EQ = 0, ORCGPU_PRED_NE = 1, ORCGPU_PRED_LT = 2, ORCGPU_PRED_LE = 3, ORCGPU_PRED_GT = 4, ORCGPU_PRED_GE = 5, /* ComparisonOp */
+       ORCGPU_PRED_IS_NULL = 6, ORCGPU_PRED_IS_NOT_NULL = 7, ORCGPU_PRED_AND = 8, ORCGPU_PRED_OR = 9, ORCGPU_PRED_NOT = 10 };
+/* PredicateValue (predicate.rs:29-47) */
+enum { ORCGPU_PV_BOOLEAN = 0, ORCGPU_PV_INT8 = 1, ORCGPU_PV_INT16 = 2, ORCGPU_PV_INT32 = 3, ORCGPU_PV_INT64 = 4, ORCGPU_PV_FLOAT32 = 5,
+       ORCGPU_PV_FLOAT64 = 6, ORCGPU_PV_UTF8 = 7 };
+typedef struct {
+  int32_t op;            /* ORCGPU_PRED_*                                                                 */
+  uint32_t n_children;   /* AND / OR                                                                      */
+  const char* column;    /* comparisons and null tests: the name of a projected root column               */
+  int32_t value_type;    /* comparisons: ORCGPU_PV_*                                                       */
+  int32_t value_is_null; /* ... Some / None                                                                */
+  int64_t i;             /* Boolean (0 / 1) and the integer kinds                                          */
+  double f;              /* Float32 / Float64                                                              */
+  const char* s;         /* Utf8: bytes, not necessarily terminated                                        */
+  uint64_t s_len;
+} orcgpu_predicate_node;
+/* What the reader knows about one column of one stripe: the plain (decompressed) bytes of its ROW_INDEX stream, a
+ * proto RowIndex, and of its BLOOM_FILTER (else BLOOM_FILTER_UTF8) stream, a proto BloomFilterIndex (NULL, 0: none). */
+typedef struct {
+  const char* name;
+  const uint8_t* row_index;
+  uint64_t row_index_len;
+  const uint8_t* bloom_index;
+  uint64_t bloom_index_len;
+} orcgpu_column_index;
+/* Host only: evaluate_predicate (row_group_filter.rs:50-165) -- which row groups of a stripe might hold rows that satisfy the
+ * predicate, judged by the row groups' statistics (min / max, null counts: :167-330, :470-620) and, for equality, their Bloom
+ * filters (:332-371, bloom_filter.rs).  keep[g] = 1: row group g must be read; *n_groups = ceil(stripe_rows / rows_per_group)
+ * (keep must have room for that many).  Anything but ORCGPU_OK means the reference's evaluation fails (a column that is not
+ * there or has no index, a value of the wrong type, a row group without typed statistics): its reader then reads every row. */
+int orcgpu_predicate_row_groups(const orcgpu_predicate_node* nodes, uint32_t n_nodes, const orcgpu_column_index* columns, uint32_t n_columns,
+                                uint64_t stripe_rows, uint64_t rows_per_group, uint8_t* keep, uint32_t* n_groups);
+/* with_predicate (arrow_reader.rs:173): per stripe the predicate is evaluated against the stripe's row indexes, the row groups
+ * it keeps become a RowSelection (RowSelection::from_row_group_filter, row_selection.rs:348-392) and the stripe is decoded under
+ * it -- here: only those row groups are read (orcgpu_reader_set_row_group_pruning).  A stripe whose evaluation fails is read
+ * whole.  The nodes (and their strings) are copied.  With a row selection as well, a row is read when both select it (the
+ * reference's own combination, arrow_reader.rs:296-308, panics unless the row selection selects every row of the stripe). */
+int orcgpu_reader_set_predicate(orcgpu_reader* r, const orcgpu_predicate_node* nodes, uint32_t n_nodes);
 /* Read-ahead: how many decoded stripes the reader may be ahead of the caller (default 4, at most 8; 0 = none: every stripe is
  * read, staged, decoded and copied back inside the orcgpu_reader_next_batch call that needs it).  With read-ahead two threads
  * of the reader work beside the caller: one reads and stages the stripes to come, one decodes the stripes staged so far

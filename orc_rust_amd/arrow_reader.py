@@ -71,6 +71,13 @@ class ArrowReaderBuilder:
         self._ctx._check(self._ctx.L.orcgpu_reader_set_row_selection(self._h, capi.selector_array(selectors), len(selectors)))
         return self
 
+    def with_predicate(self, predicate):
+        """with_predicate (arrow_reader.rs:173): a orc_rust_amd.predicate.Predicate evaluated against every stripe's row-group
+        statistics and Bloom filters; only the row groups it keeps are read."""
+        nodes, keep = predicate.flatten()
+        self._ctx._check(self._ctx.L.orcgpu_reader_set_predicate(self._h, nodes, len(nodes)))
+        return self
+
     def with_row_group_pruning(self, on):
         """Under a row selection, read only the row groups that hold selected rows (orcgpu_reader_set_row_group_pruning;
         default on).  The batches are the same either way."""

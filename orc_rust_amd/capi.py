@@ -23,7 +23,8 @@ EXPORTS = [
     "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_fetch_async", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_timezone_offsets", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
     "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
     "orcgpu_reader_set_projection", "orcgpu_reader_set_projection_roots", "orcgpu_reader_set_schema", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection", "orcgpu_reader_set_prefetch",
-    "orcgpu_reader_set_row_group_pruning", "orcgpu_reader_row_groups", "orcgpu_index_entry",
+    "orcgpu_reader_set_row_group_pruning", "orcgpu_reader_row_groups", "orcgpu_index_entry", "orcgpu_reader_set_predicate",
+    "orcgpu_predicate_row_groups",
     "orcgpu_reader_total_rows", "orcgpu_reader_stripe_count", "orcgpu_reader_column_count", "orcgpu_reader_column_name",
     "orcgpu_reader_next_batch",
 ]
@@ -145,6 +146,10 @@ def load():
     L.orcgpu_result_fetch.argtypes = [C.c_void_p, C.c_void_p]
     L.orcgpu_result_fetch_async.argtypes = [C.c_void_p, C.c_void_p]
     L.orcgpu_reader_set_prefetch.argtypes = [C.c_void_p, C.c_uint32]
+    from .predicate import ColumnIndex, PredicateNode
+    L.orcgpu_reader_set_predicate.argtypes = [C.c_void_p, C.POINTER(PredicateNode), C.c_uint32]
+    L.orcgpu_predicate_row_groups.argtypes = [C.POINTER(PredicateNode), C.c_uint32, C.POINTER(ColumnIndex), C.c_uint32, C.c_uint64, C.c_uint64,
+                                              C.c_void_p, C.POINTER(C.c_uint32)]
     L.orcgpu_reader_set_row_group_pruning.argtypes = [C.c_void_p, C.c_int]
     L.orcgpu_reader_row_groups.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.orcgpu_index_entry.argtypes = [C.POINTER(Column), C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_uint32, C.c_int32, C.POINTER(StreamEntry)]

@@ -24,6 +24,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
