@@ -561,5 +561,10 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
   PROF_END_AT(112);
   // everything this job wrote must be in memory before its status says so (the literals went out as ordinary stores)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if (lane == 0) __hip_atomic_store(&status_out[job], (uint32_t)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) {
+    __hip_atomic_store(&status_out[job], (uint32_t)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // jobs that have ended (progress[n_blocks] is the execution kernel's queue head): once all have, the workgroups of the
+    // execution kernel beside this one stop taking chunks and leave the rest to a launch that may fill the machine
+    __hip_atomic_fetch_add(progress + n_blocks + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
