@@ -37,12 +37,27 @@ struct PresJob {
   const unsigned long long* parent_vbits;  // the parent's stripe-wide validity words (null: a root column)
   const uint32_t* parent_rank;             // ... and the non-null rows before each of them
   uint64_t* ceil8b_out;            // Struct columns: ceil(nonnull / 8) = bytes of their children's PRESENT streams, else null
+  // one arm of a Union (array_decoder/union.rs:69-136): "present" where the Union is and its tag names this arm -- the validity
+  // the arm's child is decoded under.  tags: the Union's dense tags (one per row in which the Union is present: parent_vbits /
+  // parent_rank are then the Union's own words and ranks, null when it has no nulls)
+  const int8_t* tags;
+  int32_t tag;
 };
 
 __device__ __forceinline__ void present_word(const PresJob& j, uint64_t w) {
   unsigned long long v;
   uint64_t rows_here = j.n_rows - w * 64;
-  if (!j.parent_vbits) {
+  if (j.tags) {
+    const unsigned long long pv = j.parent_vbits ? j.parent_vbits[w] : ~0ull;
+    uint64_t at = j.parent_rank ? j.parent_rank[w] : w * 64;
+    const uint32_t nrow = rows_here < 64 ? (uint32_t)rows_here : 64u;
+    v = 0;
+    for (uint32_t b = 0; b < nrow; b++)
+      if ((pv >> b) & 1) {
+        if (j.tags[at] == (int8_t)j.tag) v |= 1ull << b;
+        at++;
+      }
+  } else if (!j.parent_vbits) {
     uint64_t x = ld_u64(j.pbytes + w * 8);
     // reverse the bits inside each byte: bitreverse64 reverses everything, bswap restores byte order
     v = __builtin_bswap64(__builtin_bitreverse64(x));
@@ -267,6 +282,21 @@ extern "C" __global__ void __launch_bounds__(256) space_multi_kernel(const Space
   else if (j.width == 4) space_body((const int32_t*)j.dense, j.vbits, j.rank, (int32_t*)j.out, j.n_rows);
   else if (j.width == 2) space_body((const int16_t*)j.dense, j.vbits, j.rank, (int16_t*)j.out, j.n_rows);
   else space_body((const int8_t*)j.dense, j.vbits, j.rank, (int8_t*)j.out, j.n_rows);
+}
+
+// The summary of a decode call (scalars, job records, null counts: some KB) goes to the host through this kernel -- stores into
+// the pinned, device-visible mirror -- instead of a device-to-host copy: a copy would queue behind the copies back of earlier
+// results on the same DMA engine (hundreds of MB each) and hold the decode up for as long as they take.
+extern "C" __global__ void __launch_bounds__(256) summary_to_host_kernel(const unsigned long long* src, unsigned long long* host, uint64_t n_words) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_words) __builtin_nontemporal_store(src[i], host + i);
+}
+
+// Union: a type id that names no arm cannot become a UnionArray (union.rs:126-129: UnionArray::try_new -> ArrowError)
+// (tags: the dense ones, one per row in which the Union is present; the error names the first such value)
+__device__ __forceinline__ void union_tags_body(const int8_t* tags, const uint64_t* n_tags, int32_t n_arms, unsigned long long* err) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < *n_tags && (tags[i] < 0 || tags[i] >= n_arms)) atomicMin(err, ((unsigned long long)i << 8) | ORC_E_ARROW);
 }
 
 // Float/Double without nulls: plain copy of the raw little-endian stream (float.rs:70-74).

@@ -313,6 +313,7 @@ struct ColumnOut {
   uint32_t width = 0;        // fixed width in bytes (0 for strings / boolean)
   bool is_string = false, is_bool = false;
   bool is_struct = false;    // validity only; its fields are the columns whose `parent` names it
+  bool is_union = false;     // values = the type ids (int8 per row, 0 where the Union is null); its arms' children are the columns whose `parent` names it
   bool is_list = false;      // List / Map: per-batch int32 offsets restarting at 0 (list.rs:63-87, map.rs:74-104); char_total / char_base count
                              // ELEMENTS; the elements themselves are the columns of orcgpu_result::subs[sub]
   bool is_map = false;
@@ -552,6 +553,11 @@ struct ColPlan {
   int parent_plan = -1;       // index in Plan::cols of the Struct this column is a field of (only when that one has validity)
   int depth = 0;              // Structs above it
   uint32_t ceil8_idx = 0;     // Struct: scalar holding ceil(non-null rows / 8), the length of its fields' PRESENT streams
+  // Union (union.rs:69-136): behind the Union's own plan follow its ARMS, one per child: plans without a column of their own
+  // (col = -1) that stand where a Struct stands above a field -- valid where the Union is present and its tag names the arm
+  int arm0 = -1, n_arms = 0;  // the Union: its first arm in Plan::cols
+  int arm_of = -1, arm_tag = 0;  // an arm: the Union's plan, the tag
+  uint64_t arm_validity_off = 0;  // an arm: scratch for the per-batch bitmaps nobody reads
   bool tz = false;            // TIMESTAMP of a stripe with a writer time zone: re-labelled to UTC, which can yield nulls
   PlainStream present, data, length, secondary, dict;
   // scratch

@@ -41,7 +41,7 @@ INTEGRATION = [
     "TestVectorOrcFile.testLz4.orc", "TestVectorOrcFile.testLzo.orc", "TestVectorOrcFile.testZstd.0.12.orc", "decimal.orc",
     "nulls-at-end-snappy.orc", "orc_index_int_string.orc", "orc_split_elim_new.orc",
     "orc_split_elim_cpp.orc", "over1k_bloom.orc", "bloom_filter.orc", "demo-11-zlib.orc",
-    "TestOrcFile.testSargSkipPickupGroupWithoutIndexCPlusPlus.orc", "TestOrcFile.testSargSkipPickupGroupWithoutIndexJava.orc",
+    "TestOrcFile.testUnionAndTimestamp.orc", "TestOrcFile.testSargSkipPickupGroupWithoutIndexCPlusPlus.orc", "TestOrcFile.testSargSkipPickupGroupWithoutIndexJava.orc",
 ]
 
 
