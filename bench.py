@@ -315,7 +315,7 @@ def check_sums(torch, res, cols, sums, what):
             assert got == tuple(e["offsets"]), (what, c.get("name"), "offsets differ", got, e["offsets"])
 
 
-def pipelined_end_to_end(ctx, stripes, comp, group=4, passes=2):
+def pipelined_end_to_end(ctx, stripes, comp, group=4, passes=3):
     """Host buffers in, host (pinned) Arrow buffers out, with three things in flight at once -- what the read-ahead reader does
     (orcgpu_reader_set_prefetch; the reference: async_arrow_reader.rs:165-280): a second thread stages the stripes to come
     (orcgpu_stage_stripe: host copies into pinned pieces + H2D on the copy stream), this thread decodes `group` staged
@@ -327,7 +327,7 @@ def pipelined_end_to_end(ctx, stripes, comp, group=4, passes=2):
     import threading
     ring = [None, None, None]
     dt = arrow = 0
-    for _ in range(passes):  # the first pass allocates the arenas and the pinned host copies
+    for _ in range(passes):  # the first passes allocate the arenas and the pinned host copies (three sets of results in turn)
         arrow = 0
         q = queue.Queue(maxsize=2 * group)
         failure = []

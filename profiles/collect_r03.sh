@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # tag, bench args...
   tag=$1; shift
   ( cd $R && timeout 600 python bench.py "$@" --steps 10 --warmup 3 --no-cpu 2> $O/$tag.err | tail -1 > $O/line_$tag.json )
-  ( cd $R && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw_$tag -- python3 bench.py "$@" --steps 5 --warmup 2 --no-cpu --skip-check --no-e2e > /dev/null 2> $O/prof_$tag.err )
+  ( cd $R && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw_$tag -- python3 bench.py "$@" --steps 5 --warmup 2 --no-cpu --skip-check --no-e2e > /dev/null 2> $O/prof_$tag.err )
   f=$(find $O/raw_$tag -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" $O/kernel_stats_$tag.csv
   rm -rf $O/raw_$tag
@@ -25,9 +25,13 @@ run lineitem_zstd --workload lineitem --compression zstd
 for c in snappy lz4 zlib none; do run lineitem_$c --workload lineitem --compression $c --sf 4; done
 run c2 --workload c2
 run c2_adv --workload c2-adv --rows 24000000
+run c2_adv_noindex --workload c2-adv --rows 24000000 --no-row-index
 run c2_rowgroup --workload c2-rowgroup
+run c2_rowgroup_noindex --workload c2-rowgroup --no-row-index
 for c in none snappy zstd lz4 zlib; do run c3_$c --workload c3 --compression $c; done
 run c5_lz4 --workload c5 --compression lz4
+# 3b. what a row selection / a predicate costs with row-group pruning (reader front, a file written by the ORC C++ writer)
+( cd $R && timeout 600 python profiles/select_cost.py 6000000 > $O/select_cost.json 2> $O/select_cost.err )
 # 4. HBM traffic of the headline (at SF 1: one row per dispatch is kept while collecting) and of C3 / C2: FETCH_SIZE and WRITE_SIZE
 #    in passes of their own (no trace domain beside --kernel-trace), each bounded
 pmc() {  # tag, counter, bench args...

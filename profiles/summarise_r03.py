@@ -22,6 +22,8 @@ for f in sorted(glob.glob(f'{O}/sf_*.json'), key=lambda f: float(os.path.basenam
                   "mrows_per_s": d["mrows_per_s"], "ms_per_step": d["ms_per_step"], "phase_ms": d["phase_ms"], "roofline_frac": d["roofline"]["frac"],
                   "whole_step_frac": d["roofline"]["whole_step_frac"], "generate_s": d["setup"]["generate_s"]})
 json.dump({"command": "python bench.py --sf <SF> --steps 5 --warmup 2 --no-cpu --no-e2e", "curve": curve}, open(f'{P}/r03_sf_curve.json', 'w'), indent=1)
+if os.path.exists(f'{O}/select_cost.json') and open(f'{O}/select_cost.json').read().strip():
+    json.dump(json.loads(open(f'{O}/select_cost.json').read()), open(f'{P}/r03_select_cost.json', 'w'), indent=1)
 pmc = json.load(open(f'{O}/pmc_per_kernel.json'))
 out = {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> (a pass each, no other trace domain) -- python3 bench.py --workload W "
                   "--compression C --steps 2 --warmup 1 --no-cpu --skip-check --no-e2e (lineitem: --sf 1)",
