@@ -302,3 +302,55 @@ def test_verified_run_starts():
             res = G.gpu_decode(n, cols, [(cid, kind, stream, 0, 0, bad)])
             W.check_result(res, cols, expect)
             res.free()
+
+
+@pytest.mark.parametrize("compression,block", [("none", 262144), ("zstd", 8192), ("snappy", 1024), ("lz4", 4096), ("zlib", 65536)])
+def test_entry_points_into_every_kind_of_run(compression, block):
+    """A signed RLE v2 stream of every sub-encoding (SHORT_REPEAT, DIRECT, PATCHED_BASE, fixed and varying DELTA, long and short
+    runs) entered at the positions a writer would record for row groups of 1000, 777 and 10 000 values: the column decoded from
+    an entry point on == the tail of the column decoded whole."""
+    import gpu_util as G
+    from orc_rust_amd import gen
+    rng = np.random.default_rng(17)
+    parts = []
+    for k in range(60):
+        kind = k % 6
+        m = int(rng.integers(3, 1500))
+        if kind == 0:
+            parts.append(np.full(m % 11 + 3, rng.integers(-1000, 1000)))
+        elif kind == 1:
+            parts.append(rng.integers(-(1 << int(rng.integers(2, 50))), 1 << int(rng.integers(2, 50)), m))
+        elif kind == 2:
+            v = rng.integers(0, 100, m)
+            v[rng.integers(0, m, max(1, m // 40))] = 1 << 40
+            parts.append(v)
+        elif kind == 3:
+            parts.append(np.arange(m) * int(rng.integers(-9, 9)) + int(rng.integers(-10**6, 10**6)))
+        elif kind == 4:
+            parts.append(np.cumsum(rng.integers(1, 300, m)))
+        else:
+            parts.append(np.repeat(rng.integers(0, 5, m // 4 + 1), 4)[:m])
+    vals = np.concatenate(parts).astype(np.int64)
+    n = len(vals)
+    cols = [{"column_id": 1, "orc_type": 4, "encoding": 2}]
+    for stride in (1000, 777, 10000):
+        stream, pos = gen.rle2_indexed(vals, stride, signed=True)
+        raw = bytes(stream)
+        if compression == "none":
+            framed, cpos = raw, None
+        else:
+            framed = bytes(gen.compress_stream(raw, compression, block))
+            cpos = _chunk_positions(framed, pos, block)
+        for g in sorted(set([1, len(pos) // 3, len(pos) // 2, len(pos) - 1])):
+            if g <= 0 or g >= len(pos):
+                continue
+            if cpos is None:
+                piece = (1, 1, raw[int(pos[g, 0]):], 0, int(pos[g, 1]))
+            else:
+                piece = (1, 1, framed[int(cpos[g, 0]):], int(cpos[g, 1]), int(cpos[g, 2]))
+            rows = n - g * stride
+            res = G.gpu_decode(rows, cols, [piece], compression=compression, block_size=block, batch_size=1000)
+            assert res.status()[0] == 0, (stride, g, res.status())
+            got = np.concatenate([np.frombuffer(res.batch(b, 0)["values"], dtype=np.int64) for b in range(res.n_batches)])
+            assert np.array_equal(got, vals[g * stride:]), (compression, stride, g)
+            res.free()
