@@ -486,14 +486,25 @@ __device__ __forceinline__ int utf8_lead_len(uint8_t c) {
   if (c >= 0xf0 && c <= 0xf4) return 4;
   return 0;  // continuation (0x80..0xbf) or invalid (0xc0, 0xc1, 0xf5..0xff)
 }
+// (16 bytes per thread: a vector without a byte >= 0x80 -- ASCII text, the common case -- is done with its one load)
+__device__ __forceinline__ void utf8_validate_byte(const uint8_t* s, uint64_t i, uint64_t n, unsigned long long* err);
 __device__ __forceinline__ void utf8_validate_body(const uint8_t* s, const uint64_t* scalars, uint32_t n_idx, uint32_t len_idx,
                                                                         unsigned long long* err) {
-  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
   uint64_t n = scalars[n_idx];
   if (n > scalars[len_idx]) n = scalars[len_idx];  // only bytes the stream really holds (a cut stream leaves stale ones behind)
-  if (i >= n) return;
-  uint8_t c = s[i];
-  if (c < 0x80) return;
+  if (i0 >= n) return;
+  if (i0 + 16 <= n) {
+    uint64_t v[2];
+    __builtin_memcpy(v, s + i0, 16);
+    if (((v[0] | v[1]) & 0x8080808080808080ull) == 0) return;
+  }
+  const uint64_t i1 = i0 + 16 < n ? i0 + 16 : n;
+  for (uint64_t i = i0; i < i1; i++)
+    if (s[i] >= 0x80) utf8_validate_byte(s, i, n, err);
+}
+__device__ __forceinline__ void utf8_validate_byte(const uint8_t* s, uint64_t i, uint64_t n, unsigned long long* err) {
+  const uint8_t c = s[i];
   bool bad = false;
   if ((c & 0xc0) == 0x80) {
     // continuation byte: some lead within the previous 3 bytes must cover it
@@ -615,6 +626,28 @@ __device__ __forceinline__ void varint_decode128_body(const uint8_t* s, const ui
   uint64_t k = (uint64_t)trank[p >> 6] + __builtin_popcountll(m & ((1ull << bit) - 1));
   uint64_t needed = scalars[needed_idx];
   if (k >= needed) return;
+  if (p >= 7) {
+    // the common case, a varint of at most 7 bytes: ONE load of the 8 bytes that end at p; the bytes before p that carry a
+    // continuation flag, counted from p - 1 down, are the varint's (six or fewer: else the general path below)
+    const uint64_t x = ld_u64(s + p - 7);
+    const uint64_t open = ~(x << 8) & 0x8080808080808000ull;  // flag CLEAR in bytes p - 1 (top) ... p - 7
+    const uint32_t cont = open ? (uint32_t)__builtin_clzll(open) >> 3 : 7u;
+    if (cont < 7) {
+      const uint64_t v = x >> (8 * (7 - cont));  // the varint's first byte in byte 0
+      uint64_t u = v & 0x7f;
+      u |= (v >> 1) & (0x7full << 7);
+      u |= (v >> 2) & (0x7full << 14);
+      u |= (v >> 3) & (0x7full << 21);
+      u |= (v >> 4) & (0x7full << 28);
+      u |= (v >> 5) & (0x7full << 35);
+      u |= (v >> 6) & (0x7full << 42);
+      // (bytes behind the terminator do not exist in v: the shift brought zeros in; the terminator's own flag is clear)
+      const int64_t z = (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
+      dense[k] = (__int128)z;
+      if (p == len - 1 && k + 1 < needed) report_err64(err, k + 1, ORC_E_IO);
+      return;
+    }
+  }
   uint64_t start = p;
   while (start > 0 && p - start < 20 && (s[start - 1] & 0x80)) start--;
   uint32_t nb = (uint32_t)(p - start + 1);
