@@ -342,7 +342,7 @@ int orcgpu_predicate_row_groups(const orcgpu_predicate_node* nodes, uint32_t n_n
  * whole.  The nodes (and their strings) are copied.  With a row selection as well, a row is read when both select it (the
  * reference's own combination, arrow_reader.rs:296-308, panics unless the row selection selects every row of the stripe). */
 int orcgpu_reader_set_predicate(orcgpu_reader* r, const orcgpu_predicate_node* nodes, uint32_t n_nodes);
-/* Read-ahead: how many decoded stripes the reader may be ahead of the caller (default 4, at most 8; 0 = none: every stripe is
+/* Read-ahead: how many decoded stripes the reader may be ahead of the caller (default 2 -- every result set in flight costs a pinned host copy of a stripe --, at most 8; 0 = none: every stripe is
  * read, staged, decoded and copied back inside the orcgpu_reader_next_batch call that needs it).  With read-ahead two threads
  * of the reader work beside the caller: one reads and stages the stripes to come, one decodes the stripes staged so far
  * (several per call when decoding is the slower side) and starts their copies back, while the caller consumes the batches of
