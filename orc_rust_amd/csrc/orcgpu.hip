@@ -342,6 +342,63 @@ struct ColumnOut {
 
 // Host mirror of a result's arenas: ONE device-to-host copy per arena into pinned memory; exported batches are views into
 // it and keep it alive (reference count) after the result itself is gone.
+// Pinned host memory of the result copies (orcgpu_result_fetch): pinning costs about 0.2 ms per MB, so buffers the last batch
+// has let go of are kept for the next result -- of this reader or the next (a scan over many files) -- instead of being
+// unpinned: process-wide, at most ORCGPU_PINNED_POOL_MB (default 4096) idle.
+struct PinnedPool {
+  std::mutex m;
+  std::vector<std::pair<uint8_t*, size_t>> free_list;
+  size_t idle = 0;
+  static PinnedPool& get() {
+    static PinnedPool* p = new PinnedPool();  // (never destroyed: batches may outlive every context)
+    return *p;
+  }
+  static size_t limit() {
+    static const size_t v = (size_t)(getenv("ORCGPU_PINNED_POOL_MB") ? atoll(getenv("ORCGPU_PINNED_POOL_MB")) : 4096) << 20;
+    return v;
+  }
+  bool take(size_t want, uint8_t*& ptr, size_t& cap) {
+    {
+      std::lock_guard<std::mutex> g(m);
+      int best = -1;
+      for (size_t k = 0; k < free_list.size(); k++)
+        if (free_list[k].second >= want && free_list[k].second <= 2 * want + (1u << 20) && (best < 0 || free_list[k].second < free_list[best].second)) best = (int)k;
+      if (best >= 0) {
+        ptr = free_list[best].first;
+        cap = free_list[best].second;
+        idle -= cap;
+        free_list.erase(free_list.begin() + best);
+        return true;
+      }
+    }
+    if (hipHostMalloc((void**)&ptr, want, hipHostMallocDefault) != hipSuccess) {
+      // make room: unpin what is idle, then once more
+      std::vector<std::pair<uint8_t*, size_t>> drop;
+      {
+        std::lock_guard<std::mutex> g(m);
+        drop.swap(free_list);
+        idle = 0;
+      }
+      for (auto& d : drop) (void)hipHostFree(d.first);
+      if (hipHostMalloc((void**)&ptr, want, hipHostMallocDefault) != hipSuccess) return false;
+    }
+    cap = want;
+    return true;
+  }
+  void give(uint8_t* ptr, size_t cap) {
+    if (!ptr) return;
+    {
+      std::lock_guard<std::mutex> g(m);
+      if (idle + cap <= limit() && free_list.size() < 256) {
+        free_list.push_back({ptr, cap});
+        idle += cap;
+        return;
+      }
+    }
+    (void)hipHostFree(ptr);
+  }
+};
+
 struct HostMirror {
   std::atomic<int> refs{1};
   uint8_t* arena[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
@@ -359,11 +416,11 @@ struct HostMirror {
     if (refs.fetch_sub(1) == 1) {
       wait();
       if (done) (void)hipEventDestroy(done);
-      if (sel) (void)hipHostFree(sel);
-      for (auto p : arena)
-        if (p) (void)hipHostFree(p);
-      for (auto p : chars)
-        if (p) (void)hipHostFree(p);
+      PinnedPool::get().give(sel, sel_cap);
+      for (int l = 0; l < kMaxLanes; l++) {
+        PinnedPool::get().give(arena[l], arena_cap[l]);
+        PinnedPool::get().give(chars[l], chars_cap[l]);
+      }
       delete this;
     }
   }

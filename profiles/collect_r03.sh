@@ -31,7 +31,7 @@ run c2_rowgroup_noindex --workload c2-rowgroup --no-row-index
 for c in none snappy zstd lz4 zlib; do run c3_$c --workload c3 --compression $c; done
 run c5_lz4 --workload c5 --compression lz4
 # 3b. what a row selection / a predicate costs with row-group pruning (reader front, a file written by the ORC C++ writer)
-( cd $R && timeout 600 python profiles/select_cost.py 6000000 > $O/select_cost.json 2> $O/select_cost.err )
+( cd $R && timeout 600 python profiles/select_cost.py 24000000 > $O/select_cost.json 2> $O/select_cost.err )
 # 4. HBM traffic of the headline (at SF 1: one row per dispatch is kept while collecting) and of C3 / C2: FETCH_SIZE and WRITE_SIZE
 #    in passes of their own (no trace domain beside --kernel-trace), each bounded
 pmc() {  # tag, counter, bench args...
