@@ -354,3 +354,40 @@ def test_entry_points_into_every_kind_of_run(compression, block):
             got = np.concatenate([np.frombuffer(res.batch(b, 0)["values"], dtype=np.int64) for b in range(res.n_batches)])
             assert np.array_equal(got, vals[g * stride:]), (compression, stride, g)
             res.free()
+
+
+def test_damaged_index_streams_do_not_bring_the_reader_down(tmp_path):
+    """The index section of every stripe with random bytes flipped (ROW_INDEX protobufs, their chunk framing, their compressed
+    bytes): under a selection and under a predicate the reader either reads (possibly other rows: the positions are what they
+    are), falls back to the whole decode, or reports an error -- it does not crash or run away."""
+    from orc_rust_amd.predicate import Predicate as P, PredicateValue as V
+    n = 60_000
+    table = make_table(n, seed=21)
+    for comp in ("zstd", "uncompressed"):
+        path = write(tmp_path, table, "d_%s.orc" % comp, compression=comp, compression_block_size=65536, row_index_stride=1000, stripe_size=1 << 20)
+        good = open(path, "rb").read()
+        rng = np.random.default_rng(99)
+        sel = [S(12_345), K(10), S(20_000), K(900), S(n - 12_345 - 10 - 20_000 - 900)]
+        pred = P.and_([P.gte("seq", V.Int64(1000)), P.lt("seq", V.Int64(50_000))])
+        outcomes = {"ok": 0, "error": 0}
+        for trial in range(40):
+            bad = bytearray(good)
+            for _ in range(int(rng.integers(1, 12))):
+                # half of them in the first stripe's index section (it starts behind the "ORC" magic), the rest anywhere in the stripes
+                # (index sections and data alike); the file's tail (footers) is left alone
+                p = int(rng.integers(3, 12_000)) if rng.random() < 0.5 else int(rng.integers(3, max(4, len(bad) * 7 // 10)))
+                bad[p] ^= int(rng.integers(1, 256))
+            for kind in ("selection", "predicate"):
+                try:
+                    b = ArrowReaderBuilder.try_new(bytes(bad), ctx()).with_batch_size(1000).with_prefetch(int(trial % 2) * 2)
+                    b = b.with_row_selection(sel) if kind == "selection" else b.with_predicate(pred)
+                    r = b.build()
+                    rows = sum(x.num_rows for x in r)
+                    r.close()
+                    assert rows <= n
+                    outcomes["ok"] += 1
+                except capi.OrcGpuError:
+                    outcomes["error"] += 1
+        assert outcomes["ok"] + outcomes["error"] == 80
+    # the context still decodes
+    check(table, path, [S(100), K(50), S(n - 150)], expect_pruned=True)
