@@ -163,8 +163,10 @@ def build_workload(args, rank, world):
     elif wl == "c3":
         comp = args.compression or "snappy"
         for s in mine:
-            stripes.append(W.c3_stripe(min(C2_STRIPE_ROWS, rows - s * C2_STRIPE_ROWS), s, comp))
+            stripes.append(W.c3_stripe(min(C2_STRIPE_ROWS, rows - s * C2_STRIPE_ROWS), s, comp, index=args.row_index))
         label = "C3: dictionary Utf8 (7 entries) + PRESENT (10 %% nulls), %d rows, %s, %d stripes" % (rows, comp, n_stripes)
+        if args.row_index:
+            label += ", the ROW_INDEX positions of the PRESENT and DATA streams (one per 10 000 rows) given as verified run starts"
     elif wl == "c5":
         comp = args.compression or "lz4"
         for s in mine:
@@ -419,6 +421,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--row-index", action="store_true",
+                    help="c3: stage the PRESENT and DATA streams with their ROW_INDEX positions (BASELINE's C3 is measured without)")
     ap.add_argument("--no-row-index", action="store_true",
                     help="c2-adv / c2-rowgroup: stage the stream without its ROW_INDEX positions (a file written without indexes)")
     ap.add_argument("--workload", default="lineitem", choices=["lineitem", "c2", "c2-direct", "c2-delta", "c2-arange", "c2-adv", "c2-rowgroup", "c3", "c5"],

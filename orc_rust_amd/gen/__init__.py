@@ -45,6 +45,8 @@ def lib():
         L.orcgen_rle2.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, pp, ps, C.c_void_p]
         L.orcgen_rle2_segments.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, pp, ps, C.c_void_p]
         L.orcgen_rle2_indexed.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_void_p, pp, ps]
+        L.orcgen_rle2_marked.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, pp, ps]
+        L.orcgen_byte_rle_positions.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orcgen_rle1.argtypes = [C.c_void_p, C.c_size_t, C.c_int, pp, ps]
         L.orcgen_byte_rle.argtypes = [C.c_void_p, C.c_size_t, pp, ps]
         L.orcgen_bool.argtypes = [C.c_void_p, C.c_size_t, pp, ps]
@@ -96,6 +98,26 @@ def rle2_indexed(values, stride, seg_lens=None, signed=True, aligned=False):
     out, n = C.c_void_p(), C.c_size_t()
     lib().orcgen_rle2_indexed(v.ctypes.data, v.size, sl.ctypes.data, sl.size, int(signed), int(aligned), stride, pos.ctypes.data, C.byref(out), C.byref(n))
     return _take(out, n), pos
+
+
+def rle2_marked(values, marks, signed=True, aligned=False):
+    """RLE v2 and the positions [marks, 2] = (bytes written, values the encoder held) of the values `marks` (ascending indices): a
+    column with nulls, whose row groups start at the count of non-null rows before them."""
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    mk = np.ascontiguousarray(marks, dtype=np.uint64)
+    pos = np.zeros((mk.size, 2), dtype=np.uint64)
+    out, n = C.c_void_p(), C.c_size_t()
+    lib().orcgen_rle2_marked(v.ctypes.data, v.size, None, 0, int(signed), int(aligned), 0, mk.ctypes.data, mk.size, pos.ctypes.data, C.byref(out), C.byref(n))
+    return _take(out, n), pos
+
+
+def byte_rle_positions(stream, marks):
+    """Positions [marks, 2] = (offset of the group's header, values of the group in front) of the values `marks` of a byte-RLE stream."""
+    s = np.frombuffer(bytes(stream), dtype=np.uint8)
+    mk = np.ascontiguousarray(marks, dtype=np.uint64)
+    pos = np.zeros((mk.size, 2), dtype=np.uint64)
+    lib().orcgen_byte_rle_positions(s.ctypes.data, s.size, mk.ctypes.data, mk.size, pos.ctypes.data)
+    return pos
 
 
 def rle1(values, signed=True):

@@ -412,17 +412,31 @@ int orcgen_rle2_segments(const int64_t* vals, size_t n, const uint32_t* seg_lens
 /* Public: orcgen_rle2_segments (n_seg = 0: no forced flushes) that also records, as a writer does for its ROW_INDEX streams, the
  * position of every `stride`-th value: positions[2g] = bytes written when value g * stride arrives, positions[2g + 1] = values
  * the encoder holds at that moment (they open the run(s) that start at that byte).  ceil(n / stride) pairs. */
+int orcgen_rle2_marked(const int64_t* vals, size_t n, const uint32_t* seg_lens, size_t n_seg, int is_signed, int aligned, uint32_t stride,
+                       const uint64_t* marks, size_t n_marks, uint64_t* positions, uint8_t** out, size_t* out_len);
 int orcgen_rle2_indexed(const int64_t* vals, size_t n, const uint32_t* seg_lens, size_t n_seg, int is_signed, int aligned, uint32_t stride,
                         uint64_t* positions, uint8_t** out, size_t* out_len) {
+  return orcgen_rle2_marked(vals, n, seg_lens, n_seg, is_signed, aligned, stride, NULL, 0, positions, out, out_len);
+}
+/* ... or of the values marks[0] < marks[1] < ... (a column with nulls: the value a row group starts with is the count of
+ * non-null rows before it); a mark == n (no value behind it) gets the end of the stream */
+int orcgen_rle2_marked(const int64_t* vals, size_t n, const uint32_t* seg_lens, size_t n_seg, int is_signed, int aligned, uint32_t stride,
+                       const uint64_t* marks, size_t n_marks, uint64_t* positions, uint8_t** out, size_t* out_len) {
   obuf b = {0, 0, 0};
   rle2* e = (rle2*)calloc(1, sizeof(rle2));
   e->out = &b;
   e->is_signed = is_signed;
   e->aligned = aligned;
-  size_t i = 0, k = 0;
+  size_t i = 0, k = 0, m = 0;
   uint32_t in_seg = 0;
   for (; i < n; i++) {
-    if (stride && i % stride == 0) {
+    if (marks) {
+      while (m < n_marks && marks[m] == i) {
+        positions[2 * m] = b.len;
+        positions[2 * m + 1] = (uint64_t)e->n;
+        m++;
+      }
+    } else if (stride && i % stride == 0) {
       positions[2 * (i / stride)] = b.len;
       positions[2 * (i / stride) + 1] = (uint64_t)e->n;
     }
@@ -434,10 +448,39 @@ int orcgen_rle2_indexed(const int64_t* vals, size_t n, const uint32_t* seg_lens,
     }
   }
   rle2_flush(e);
+  for (; marks && m < n_marks; m++) {
+    positions[2 * m] = b.len;
+    positions[2 * m + 1] = 0;
+  }
   free(e);
   ob_reserve(&b, 64);
   *out = b.p;
   *out_len = b.len;
+  return 0;
+}
+
+/* Public: where the values marks[0] < marks[1] < ... of a byte-RLE stream lie: positions[2m] = offset of the header of the run /
+ * literal group that holds value marks[m], positions[2m + 1] = values of that group in front of it (what a writer records for
+ * a byte-RLE stream: row_index.rs:42-50).  A mark behind the last value gets the end of the stream. */
+int orcgen_byte_rle_positions(const uint8_t* s, size_t len, const uint64_t* marks, size_t n_marks, uint64_t* positions) {
+  size_t p = 0, m = 0;
+  uint64_t v = 0;
+  while (p < len && m < n_marks) {
+    const uint8_t c = s[p];
+    const uint64_t cnt = c < 0x80 ? (uint64_t)c + 3 : 256 - (uint64_t)c;
+    const size_t size = c < 0x80 ? 2 : 1 + (size_t)cnt;
+    while (m < n_marks && marks[m] < v + cnt) {
+      positions[2 * m] = p;
+      positions[2 * m + 1] = marks[m] - v;
+      m++;
+    }
+    v += cnt;
+    p += size;
+  }
+  for (; m < n_marks; m++) {
+    positions[2 * m] = len;
+    positions[2 * m + 1] = 0;
+  }
   return 0;
 }
 

@@ -29,6 +29,7 @@ run c2_adv_noindex --workload c2-adv --rows 24000000 --no-row-index
 run c2_rowgroup --workload c2-rowgroup
 run c2_rowgroup_noindex --workload c2-rowgroup --no-row-index
 for c in none snappy zstd lz4 zlib; do run c3_$c --workload c3 --compression $c; done
+for c in none snappy; do run c3_${c}_index --workload c3 --compression $c --row-index; done
 run c5_lz4 --workload c5 --compression lz4
 # 3b. what a row selection / a predicate costs with row-group pruning (reader front, a file written by the ORC C++ writer)
 ( cd $R && timeout 600 python profiles/select_cost.py 24000000 > $O/select_cost.json 2> $O/select_cost.err )

@@ -391,3 +391,16 @@ def test_damaged_index_streams_do_not_bring_the_reader_down(tmp_path):
         assert outcomes["ok"] + outcomes["error"] == 80
     # the context still decodes
     check(table, path, [S(100), K(50), S(n - 150)], expect_pruned=True)
+
+
+@pytest.mark.parametrize("compression", ["none", "snappy", "zstd"])
+def test_verified_run_starts_of_a_column_with_nulls(compression):
+    """C3's shape (dictionary keys in short runs, PRESENT with 10 % nulls) with the positions of both run-length streams: the
+    DATA stream's row groups start at the count of non-null rows before them, the PRESENT stream's at whole bytes."""
+    import gpu_util as G
+    from orc_rust_amd.gen import workloads as W
+    n, cols, streams, expect = W.c3_stripe(300_000, 2, compression, index=True)
+    res = G.gpu_decode(n, cols, streams, compression=compression)
+    W.check_result(res, cols, expect)
+    G.assert_column_parity(res, 0, cols[0], [s[:3] for s in streams], n, 8192, compression=compression, what=("c3 entries", compression))
+    res.free()
