@@ -24,6 +24,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <sys/mman.h>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
