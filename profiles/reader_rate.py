@@ -25,8 +25,9 @@ class ArrowArray(C.Structure):
 class ArrowSchema(C.Structure):
     _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_void_p), ("flags", C.c_int64), ("n_children", C.c_int64),
                 ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.CFUNCTYPE(None, C.c_void_p)), ("private_data", C.c_void_p)]
-for bs in (8192,):
-    for prefetch in (0, 1, 2, 3, 4):
+out = {"file": {"rows": rows, "bytes": os.path.getsize(path), "arrow_bytes": arrow_bytes}, "runs": []}
+for bs in (8192, 65536):
+    for prefetch in (0, 2):
         best = None
         for _ in range(3):
             h = C.c_void_p()
