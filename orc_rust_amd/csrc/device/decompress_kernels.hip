@@ -6,7 +6,8 @@
 // format, RFC 8878).  Chunk framing (3-byte headers, compression.rs:113-123, :244-267) is scanned
 // on the host while staging; every chunk -- compressed or "original" -- becomes one ChunkDesc.
 //
-//   Zstandard     zstd_entropy.h (one wavefront per block: FSE / Huffman) -> lz_exec.h (one workgroup per chunk: the copies)
+//   Zstandard     zstd_entropy.h (one wavefront per block: FSE / Huffman) -> lz_exec.h (one workgroup per chunk: the copies);
+//                 at table scale the sequences go one LANE per block: zstd_lanes.h
 //   Snappy, LZ4   lz_parse.h (one workgroup per chunk: the tokens)          -> lz_exec.h
 //   DEFLATE       inflate_device.h: one wavefront per chunk, Huffman decode and copies through an LDS ring (this file)
 //   LZO           lzo_device.h: one wavefront per chunk, through the same LDS ring
@@ -212,6 +213,7 @@ __device__ __forceinline__ void lzin_literal(LzIn& in, LzOut& o, uint32_t pos, u
 #include "inflate_device.h"
 #include "zstd_device.h"
 #include "zstd_entropy.h"
+#include "zstd_lanes.h"
 #include "lz_parse.h"
 #include "lz_exec.h"
 #include "inflate_parse.h"

@@ -35,6 +35,17 @@ struct ZBlock {
   uint32_t pad[2];
 };
 
+struct ZSeqHdr {      // written by zstd_entropy_kernel (tables mode) per block with sequences
+  uint32_t bit_off;   // where the sequences' bit stream starts in the chunk payload
+  uint32_t logs;      // table logs: LL | OF << 8 | ML << 16
+  uint32_t status;    // nonzero: a table description is broken (the code zstd_entropy_kernel would report)
+  uint32_t pad;
+};
+#define ZL_CELLS 1280u  // cells per block: LL [0, 512), ML [512, 1024), OF [1024, 1280)
+#define ZL_LL 0u
+#define ZL_ML 512u
+#define ZL_OF 1024u
+
 struct ZFse {  // one decoding table cell
   uint16_t next;   // base of the next state
   uint8_t nb;      // bits to read for the next state
@@ -52,8 +63,13 @@ struct ZEntLds {
     struct {  // sequences phase
       ZFse ll[512], ml[512], of[256];
       ZFse zero;           // all-zero cell for the lanes without a field
-      uint32_t seqbuf[64 * 3 + 64];  // 64 decoded sequences waiting for their coalesced store (+ a sink for the idle lanes)
-      __attribute__((aligned(8))) uint8_t bits[2048 + 16];  // the piece of the bit stream the state machine is working in
+      union {
+        struct {
+          uint32_t seqbuf[64 * 3 + 64];  // 64 decoded sequences waiting for their coalesced store (+ a sink for the idle lanes)
+          __attribute__((aligned(8))) uint8_t bits[2048 + 16];  // the piece of the bit stream the state machine is working in
+        };
+        __attribute__((aligned(16))) uint16_t ctab[1280];  // tables mode (zstd_lanes.h): the block's tables as 2-byte cells {symbol : 6, state number : 10}
+      };
     } s;
   };
   int16_t norm[256];
@@ -65,7 +81,8 @@ struct ZEntLds {
 // Lane s works for symbol s (at most 53 symbols): the cells are spread over the table in closed form when no symbol has
 // the "less than one" probability (else by lane 0, cell after cell), then every lane walks the table once and numbers
 // the cells of its own symbol in ascending order -- the order that fixes each cell's next-state base (RFC 8878 4.1.1).
-__device__ __forceinline__ int zfse_build(ZFse* t, uint8_t* symtab, const int16_t* norm, int nsym, int log, uint16_t* next, int which, uint32_t lane) {
+__device__ __forceinline__ int zfse_build(ZFse* t, uint8_t* symtab, const int16_t* norm, int nsym, int log, uint16_t* next, int which, uint32_t lane,
+                                          uint16_t* ct = nullptr) {
   const int size = 1 << log;
   const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
   const int cnt = (int)lane < nsym ? (int)norm[lane] : 0;
@@ -111,6 +128,7 @@ __device__ __forceinline__ int zfse_build(ZFse* t, uint8_t* symtab, const int16_
       e.add = add;
       e.base = base;
       t[i] = e;
+      if (ct) ct[i] = (uint16_t)(lane | ns << 6);
       ns++;
     }
   }
@@ -120,7 +138,7 @@ __device__ __forceinline__ int zfse_build(ZFse* t, uint8_t* symtab, const int16_
 
 // One table description (Predefined / RLE / FSE_Compressed) at p: builds it when `build`, returns the bytes it takes or -1.
 __device__ __forceinline__ long zfse_table(ZEntLds& L, ZFse* t, int* log_out, int mode, const uint8_t* p, uint32_t n, int which, bool build,
-                                            uint32_t lane) {
+                                            uint32_t lane, uint16_t* ct = nullptr) {
   const int16_t* def = which == 0 ? Z_LL_DEF : (which == 1 ? Z_OF_DEF : Z_ML_DEF);
   const int defn = which == 0 ? 36 : (which == 1 ? 29 : 53), deflog = which == 1 ? 5 : 6;
   const int maxsym = which == 0 ? 36 : (which == 1 ? 32 : 53), maxlog = which == 1 ? 8 : 9;
@@ -128,7 +146,7 @@ __device__ __forceinline__ long zfse_table(ZEntLds& L, ZFse* t, int* log_out, in
     if (build) {
       for (int i = (int)lane; i < defn; i += 64) L.norm[i] = def[i];
       wave_sync();
-      if (zfse_build(t, L.sym, L.norm, defn, deflog, L.next, which, lane)) return -1;
+      if (zfse_build(t, L.sym, L.norm, defn, deflog, L.next, which, lane, ct)) return -1;
       *log_out = deflog;
     }
     return 0;
@@ -145,6 +163,7 @@ __device__ __forceinline__ long zfse_table(ZEntLds& L, ZFse* t, int* log_out, in
         e.add = which == 0 ? Z_LL_BITS[s] : (which == 1 ? (uint8_t)s : Z_ML_BITS[s]);
         e.base = which == 0 ? Z_LL_BASE[s] : (which == 1 ? 1u << s : Z_ML_BASE[s]);
         t[0] = e;
+        if (ct) ct[0] = (uint16_t)(s | 1u << 6);
       }
       wave_sync();
       *log_out = 0;
@@ -156,7 +175,7 @@ __device__ __forceinline__ long zfse_table(ZEntLds& L, ZFse* t, int* log_out, in
     const long c = fse_read_ncount_dev(p, n, L.norm, &nsym, &log, maxlog, lane);
     if (c < 0) return -1;
     if (build) {
-      if (zfse_build(t, L.sym, L.norm, nsym, log, L.next, which, lane)) return -1;
+      if (zfse_build(t, L.sym, L.norm, nsym, log, L.next, which, lane, ct)) return -1;
       *log_out = log;
     }
     return c;
@@ -167,13 +186,13 @@ __device__ __forceinline__ long zfse_table(ZEntLds& L, ZFse* t, int* log_out, in
 // The table `which` (0 LL, 1 OF, 2 ML) as described in the block whose modes byte sits at src[moff] (block ends at src[mend]).
 // Returns the bytes the description takes (what the OWN block's parse advances by), or -1.
 __device__ __forceinline__ long zfse_from_block(ZEntLds& L, ZFse* t, int* log_out, const uint8_t* src, uint32_t moff, uint32_t mend, int which,
-                                                 uint32_t lane) {
+                                                 uint32_t lane, uint16_t* ct = nullptr) {
   if (moff >= mend) return -1;
   const uint32_t modes = src[moff];
   uint32_t p = moff + 1;
   for (int w = 0; w <= which; w++) {
     const int mode = (modes >> (6 - 2 * w)) & 3;
-    if (w == which) return zfse_table(L, t, log_out, mode, src + p, mend - p, w, true, lane);
+    if (w == which) return zfse_table(L, t, log_out, mode, src + p, mend - p, w, true, lane, ct);
     if (mode == 3) continue;  // a repeated table takes no bytes
     const long c = zfse_table(L, t, log_out, mode, src + p, mend - p, w, false, lane);
     if (c < 0) return -1;
@@ -468,8 +487,10 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
 // Both are read by the execution kernel while this one runs: status words start as ZSTD_PENDING, progress[b] counts the sequences
 // of block b that are in memory.
 #define ZSTD_PENDING 0xffffffffu
+// Tables mode (ztab != nullptr; zstd_lanes.h): a sequences job only builds the block's tables and leaves them in ztab / zhdr;
+// zstd_seq_lanes_kernel, behind this kernel, decodes the sequences and writes the job's status word.
 extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBlock* __restrict__ blocks, uint32_t n_blocks, uint32_t* dump_words,
-                                                                     uint32_t* status_out, uint32_t* progress) {
+                                                                     uint32_t* status_out, uint32_t* progress, uint16_t* ztab, ZSeqHdr* zhdr) {
   __shared__ ZEntLds L;
   const uint32_t job = blockIdx.x;
   if (job >= 2 * n_blocks) return;
@@ -540,17 +561,34 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
     for (int w = 0; w < 3 && !st; w++) {
       ZFse* t = w == 0 ? L.s.ll : (w == 1 ? L.s.of : L.s.ml);
       int* lg = w == 0 ? &ll_log : (w == 1 ? &of_log : &ml_log);
+      uint16_t* ct = ztab ? L.s.ctab + (w == 0 ? ZL_LL : (w == 1 ? ZL_OF : ZL_ML)) : nullptr;
       if (B.tab_off[w] == B.seq_off) {
         const int mode = (src[B.seq_off] >> (6 - 2 * w)) & 3;
-        const long c = p <= end ? zfse_table(L, t, lg, mode, src + p, end - p, w, true, lane) : -1;
+        const long c = p <= end ? zfse_table(L, t, lg, mode, src + p, end - p, w, true, lane, ct) : -1;
         if (c < 0) st = 17 + w;
         else p += (uint32_t)c;
       } else {
-        if (zfse_from_block(L, t, lg, src, B.tab_off[w], B.tab_end[w], w, lane) < 0) st = 17 + w;
+        if (zfse_from_block(L, t, lg, src, B.tab_off[w], B.tab_end[w], w, lane, ct) < 0) st = 17 + w;
       }
     }
     wave_sync();
     PROF_MARK(3);
+    if (ztab) {
+      // tables mode: the cells go to memory (16 bytes per lane and step), the sequences are another kernel's
+      uint4* g = reinterpret_cast<uint4*>((uint16_t*)as_global((void*)ztab) + (size_t)b * ZL_CELLS);
+      const uint4* l = reinterpret_cast<const uint4*>(L.s.ctab);
+      for (uint32_t k = lane; k < ZL_CELLS * 2 / 16; k += 64) g[k] = l[k];
+      if (lane == 0) {
+        ZSeqHdr h;
+        h.bit_off = p;
+        h.logs = (uint32_t)ll_log | (uint32_t)of_log << 8 | (uint32_t)ml_log << 16;
+        h.status = (uint32_t)st;
+        h.pad = 0;
+        *(ZSeqHdr*)as_global((void*)(zhdr + b)) = h;
+      }
+      PROF_END_AT(112);
+      return;
+    }
     if (!st) {
       if (p > end) st = 20;
       else st = zfse_sequences(L, src + p, end - p, B.nseq, ll_log, of_log, ml_log, seq_out, dump, (uint32_t*)as_global((void*)(progress + b)), lane);

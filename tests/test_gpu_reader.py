@@ -57,6 +57,41 @@ def test_read_file_matches_expectation(name):
         assert got.equals(want), (name, cname)
 
 
+@pytest.mark.parametrize("prefetch", [0, 2])
+def test_empty_projection_gives_row_counts_only(prefetch):
+    """No column projected (array_decoder/mod.rs:534-549): the reference still yields one RecordBatch per batch of every stripe,
+    without columns, whose row count is min(batch size, rows left in the stripe)."""
+    path = A.data_path("TestOrcFile.testSeek.orc")  # 7 stripes, 32768 rows
+    _, f = flat_names(path)
+    r = ArrowReaderBuilder.try_new(path, ctx()).with_projection([]).with_batch_size(1000).with_prefetch(prefetch).build()
+    assert r.column_names() == []
+    batches = list(r)
+    assert all(b.num_columns == 0 for b in batches)
+    want = []
+    for st in f.stripes:
+        left = st.number_of_rows
+        while left:
+            want.append(min(1000, left))
+            left -= want[-1]
+    assert [b.num_rows for b in batches] == want and sum(want) == 32768
+    # ... and under a row selection: the selected rows are counted (mod.rs:302-365)
+    r = ArrowReaderBuilder.try_new(path, ctx()).with_projection([]).with_batch_size(1000).with_prefetch(prefetch)
+    r = r.with_row_selection([(100, True), (2500, False), (30168, True)]).build()
+    got = [b.num_rows for b in r]
+    import selection_model as M
+    model = M.file_batches([(100, True), (2500, False), (30168, True)], [st.number_of_rows for st in f.stripes], 1000)
+    want = []
+    for st, per in zip(f.stripes, model):
+        if per is None:  # (a selection with no rows left no longer applies: the stripe is read whole, arrow_reader.rs:296-308)
+            left = st.number_of_rows
+            while left:
+                want.append(min(1000, left))
+                left -= want[-1]
+        else:
+            want += [ln for _, ln in per]
+    assert got == want
+
+
 def test_builder_knobs():
     path = A.data_path("TestOrcFile.testSeek.orc")  # 7 stripes, 32768 rows
     names, f = flat_names(path)

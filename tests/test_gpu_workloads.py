@@ -78,6 +78,20 @@ def test_c3_dictionary_utf8_with_present(compression):
         res.free()
 
 
+def test_c2_direct_delta_stripes():
+    """BASELINE config C2 as bench.py runs it (`--workload c2`): one DIRECT stripe (40-bit values, byte-aligned 512-value
+    runs) and one DELTA stripe (8-bit deltas) in ONE call, > 1 M rows each, against the generator's values and the oracle."""
+    stripes = [W.c2_stripe(1_200_000, 0, "direct"), W.c2_stripe(1_100_003, 1, "delta", base=7)]
+    assert stripes[0][4]["direct"] == (1_200_000 + 511) // 512 and stripes[1][4]["delta"] == (1_100_003 + 511) // 512
+    results = decode_all([s[:4] for s in stripes], "none")
+    for (n, cols, streams, expect, _), res, kind in zip(stripes, results, ("direct", "delta")):
+        assert res.status()[0] == 0, res.status()
+        assert res.rows == n and res.n_batches == (n + 8191) // 8192
+        W.check_result(res, cols, expect)
+        G.assert_column_parity(res, 0, cols[0], streams, n, 8192, what=("C2", kind))
+        res.free()
+
+
 def test_c2_adversarial_walk():
     """Run lengths 200..511 with the width changing from run to run and PATCHED_BASE runs in between: no stride guess of the run
     walk holds, the verify + repair kernels carry the stream (rle_scan.hip).  Decoded values = generated values = oracle."""

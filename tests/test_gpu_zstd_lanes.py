@@ -1,0 +1,113 @@
+"""GPU parity, Zstandard sequences one LANE per block (device/zstd_lanes.h).  The library takes that path by itself only
+for calls with tens of millions of sequences (bench.py's table); ORCGPU_ZSTD_LANES=1 forces it, so the same inputs the
+wavefront-per-block kernel is tested with go through it here: real encoder output over the ten data shapes at three
+block sizes (one chain .. 600 chains per call, ragged last wavefront), lineitem stripes against the oracle and the
+generator's expectations, and the differential fuzz (valid and corrupted Zstandard stripes: same failing batch, same
+error kind as the oracle).  Both wavefront shapes (16 and 64 chains) run."""
+import numpy as np
+import pytest
+
+import fuzz_gen as F
+import gpu_util as G
+from orc_rust_amd.gen import workloads as W
+from test_gpu_codecs import CODECS, DATA, DOUBLE, frame, shapes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["16", "64"])
+def lanes(request, monkeypatch):
+    monkeypatch.setenv("ORCGPU_ZSTD_LANES", "1")
+    monkeypatch.setenv("ORCGPU_ZSTD_LANES_NCH", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("block", [262144, 65536, 1000])
+def test_real_encoder_over_data_shapes(lanes, block):
+    for name, raw in shapes(block).items():
+        c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+        st = [(1, DATA, frame(raw, CODECS["zstd"], block))]
+        n = len(raw) // 8
+        res = G.gpu_decode(n, [c], st, compression="zstd", block_size=block)
+        assert res.status()[0] == 0, (block, name, res.status())
+        G.assert_column_parity(res, 0, c, st, n, 8192, compression="zstd", block_size=block, what=("lanes", lanes, block, name))
+        res.free()
+
+
+def test_all_columns_of_one_call_share_the_wavefronts(lanes):
+    """Every shape as a column of ONE stripe: chains of very different lengths side by side in a wavefront."""
+    block = 4096
+    cols, streams, rows = [], [], []
+    for name, raw in shapes(7).items():
+        cid = len(cols) + 1
+        cols.append({"column_id": cid, "orc_type": DOUBLE, "encoding": 0})
+        streams.append((cid, DATA, frame(raw, CODECS["zstd"], block)))
+        rows.append(len(raw) // 8)
+    n = min(r for r in rows if r)
+    keep = [i for i, r in enumerate(rows) if r >= n and r]
+    cols, streams = [cols[i] for i in keep], [streams[i] for i in keep]
+    res = G.gpu_decode(n, cols, streams, compression="zstd", block_size=block)
+    for ci, c in enumerate(cols):
+        G.assert_column_parity(res, ci, c, streams, n, 8192, compression="zstd", block_size=block, what=("lanes one call", lanes, ci))
+    res.free()
+
+
+def test_lineitem_stripes(lanes):
+    rows = 420_000
+    table = W.lineitem_table(rows)
+    stripes = [W.lineitem_stripe(table, 0, 300_000, "zstd"), W.lineitem_stripe(table, 300_000, rows, "zstd")]
+    c = G.ctx()
+    staged = [c.stage(n, streams, cols, compression="zstd") for n, cols, streams, _ in stripes]
+    results = c.decode(staged)
+    for s in staged:
+        s.free()
+    for (n, cols, streams, expect), res in zip(stripes, results):
+        assert res.status()[0] == 0, res.status()
+        W.check_result(res, cols, expect)
+        for ci, cc in enumerate(cols):
+            G.assert_column_parity(res, ci, cc, streams, n, 8192, compression="zstd", what=("lanes C4", lanes, cc["name"]))
+        res.free()
+
+
+def zstd_cases(first, count, corrupt):
+    out, seed = [], first
+    while len(out) < count:
+        if F.make_case(seed, corrupt)[1] == "zstd":
+            out.append(seed)
+        seed += 1
+    return out
+
+
+def test_differential_fuzz(lanes):
+    for corrupt, first in ((False, 7_000_000), (True, 7_100_000)):
+        for seed in zstd_cases(first, 60, corrupt):
+            n, comp, block, batch, cols, streams, _ = F.make_case(seed, corrupt)
+            res = G.gpu_decode(n, cols, streams, compression=comp, block_size=block, batch_size=batch)
+            try:
+                for ci, cc in enumerate(cols):
+                    G.assert_column_parity(res, ci, cc, streams, n, batch, compression=comp, block_size=block, what=("lanes", lanes, seed, corrupt))
+            finally:
+                res.free()
+
+
+def test_corrupted_sequence_sections_fail_like_the_oracle(lanes):
+    """One byte of the SEQUENCES section of a block overwritten (table descriptions, the bit stream's last byte, its middle):
+    the chunk is rejected or decodes to the same bytes as in the oracle."""
+    rng = np.random.default_rng(11)
+    text = shapes(3)["text"][:160000]
+    good = frame(text, CODECS["zstd"], 65536)
+    c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+    n = len(text) // 8
+    for trial in range(40):
+        bad = good.copy()
+        # the sequences section ends the chunk: hit its tail (bit stream) or somewhere behind the literals
+        hdr = int(bad[0]) | int(bad[1]) << 8 | int(bad[2]) << 16
+        clen = hdr >> 1
+        pos = 3 + (clen - 1 - int(rng.integers(0, 4)) if trial % 2 == 0 else int(rng.integers(clen // 2, clen)))
+        bad[pos] = rng.integers(0, 256)
+        st = [(1, DATA, bad)]
+        res = G.gpu_decode(n, [c], st, compression="zstd", block_size=65536)
+        try:
+            G.assert_column_parity(res, 0, c, st, n, 8192, compression="zstd", block_size=65536, what=("lanes corrupt", lanes, trial, pos))
+        finally:
+            res.free()
