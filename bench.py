@@ -128,8 +128,14 @@ def build_workload(args, rank, world):
             gen.lib().orcgen_lineitem_warm(7)  # the comment text pool: built once here, inherited by the forked workers
         t0 = time.perf_counter()
         if nproc > 1:
-            with mp.get_context("fork").Pool(nproc) as pool:
+            # (close + join, never terminate: under rocprofv3 a worker that gets SIGTERM can hang in the profiler's signal handler,
+            # and the run with it)
+            pool = mp.get_context("fork").Pool(nproc)
+            try:
                 stripes = pool.map(W.lineitem_unit_task, tasks, chunksize=1)
+            finally:
+                pool.close()
+                pool.join()
         else:
             stripes = [W.lineitem_unit_task(t) for t in tasks]
         gen_s = time.perf_counter() - t0
@@ -255,11 +261,15 @@ def cpu_baseline(stripes, comp, budget_s=12.0):
         ntask = int(max(4 * cores, min(16 * cores, budget_s * cores / per_task)))
         sel = list(range(ntask))
         sel.sort(key=lambda i: -sum(len(v) for v in tasks[i % len(tasks)][2].values()))  # longest first
-        with mp.get_context("fork").Pool(cores) as pool:
+        pool = mp.get_context("fork").Pool(cores)
+        try:
             pool.map(_oracle_stripe, sel[:cores], chunksize=1)  # start the workers (library load) outside the timed region
             t0 = time.perf_counter()
             res = pool.map(_oracle_stripe, sel, chunksize=1)
             dtn = time.perf_counter() - t0
+        finally:
+            pool.close()
+            pool.join()
         busy = sum(r[2] for r in res)
         out["all_cores"] = {"value": round(sum(r[1] for r in res) / dtn / 1e9, 4), "unit": "GB/s", "cores": cores,
                             "mrows_per_s": round(sum(r[0] for r in res) / ncols / dtn / 1e6, 3),

@@ -230,18 +230,47 @@ __device__ __forceinline__ int huf_build_dev(uint16_t* tab, int* maxbits_out, ui
 // bits below the start of the stream read as zero.
 struct HBits {
   const uint8_t* p;
-  uint64_t w;
-  int pos, avail;
+  uint64_t lo, hi1;  // stream bits [wb64 - 64, wb64) and [wb64, wb64 + 64) (the latter kept shifted left by one)
+  uint64_t nx;       // the eight bytes below lo, as loaded: on their way while lo and hi are consumed
+  uint32_t nxs;      // ... and the shift that zeroes what lies before the stream
+  int wb64;          // multiple of 8; 0 <= pos - wb64 <= 63 always
+  int pos;
 };
+// 64 stream bits from bit `wb` (a multiple of 8; may lie before the stream: those bits read as zero) of the stream at q
+__device__ __forceinline__ uint64_t zl_word(const uint8_t* q, int wb) {
+  const int bo = wb >> 3;
+  const uint64_t v = ld_u64(q + (bo < 0 ? 0 : bo));
+  const int neg = bo < 0 ? -bo : 0;  // bytes of the word that lie before the stream
+  return neg >= 8 ? 0ull : v << (8 * neg);
+}
+__device__ __forceinline__ void hb_fetch(HBits& h, int wb) {
+  const int bo = wb >> 3;
+  h.nx = ld_u64(h.p + (bo < 0 ? 0 : bo));
+  h.nxs = bo < 0 ? (uint32_t)(-bo) * 8u : 0u;
+}
+// A seek costs three loads; stepping down the stream afterwards never waits for memory: the word below the window is requested
+// when the window moves and needed only when it moves again (eight bytes of codes later).  The loop used to reload its window
+// from the cursor's byte position -- a dependent load every five or six symbols in SOME lane of the wavefront, i.e. in every
+// iteration of all of them.
 __device__ __forceinline__ void hb_seek(HBits& h, int pos) {
   h.pos = pos;
-  const int bytepos = (pos + 7) >> 3;  // first byte at or above pos
-  uint64_t v;
-  if (bytepos >= 8) v = ld_u64(h.p + bytepos - 8);
-  else v = bytepos > 0 ? ld_u64(h.p) << (8 * (8 - bytepos)) : 0;
-  const int waste = 8 * bytepos - pos;  // 0..7 bits at the top that lie above pos
-  h.w = v << waste;
-  h.avail = 64 - waste;
+  h.wb64 = (pos & ~7) - 56;
+  h.hi1 = zl_word(h.p, h.wb64) << 1;
+  h.lo = zl_word(h.p, h.wb64 - 64);
+  hb_fetch(h, h.wb64 - 128);
+}
+__device__ __forceinline__ uint32_t hb_peek32(const HBits& h) {  // the 32 bits below pos, bit 31 = the next unread bit
+  const uint32_t s = (uint32_t)(h.pos - h.wb64);
+  return (uint32_t)(((h.lo >> s) | (h.hi1 << (63u - s))) >> 32);
+}
+__device__ __forceinline__ void hb_skip(HBits& h, int nb) {
+  h.pos -= nb;
+  if (h.pos < h.wb64) {
+    h.hi1 = h.lo << 1;
+    h.lo = h.nxs >= 64u ? 0ull : h.nx << h.nxs;
+    h.wb64 -= 64;
+    hb_fetch(h, h.wb64 - 128);
+  }
 }
 
 __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const uint8_t* sp, uint32_t sn, uint8_t* out, uint32_t outn, uint32_t k,
@@ -253,7 +282,7 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
     if (!rb_init(r, sp, sn)) bad = 1;
     top = (int)r.bits;
   }
-  HBits h{sp, 0, 0, 0};
+  HBits h{sp, 0, 0, 0, 0, 0, 0};
   const int B = (top + (int)lps - 1) / (int)lps;
   int pk = top - (int)k * B, pn = k + 1 == lps ? 0 : top - (int)(k + 1) * B;
   if (pk < 0) pk = 0;
@@ -261,34 +290,81 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
   int start = pk, endpos = pk;
   uint32_t cnt = 0;
   const bool work = on && !bad;
+  // Round 0 decodes every segment from its nominal start; a lane then takes the point where its predecessor crossed into its
+  // segment as its true start, a few bits further down.  The new path meets the old one within a few symbols (prefix codes
+  // re-synchronise) and is the same from there on: round 0 notes where it stood after 16, 64, 256 and 1024 symbols, round 1
+  // decodes only until it stands on one of those marks.  Lanes whose start did not change keep what they have.
+  int ck0 = -1, ck1 = -1, ck2 = -1, ck3 = -1;
+  bool redo = true;
   for (uint32_t round = 0; round < lps; round++) {
-    cnt = 0;
-    endpos = start;
-    if (work && start > pn) {
-      hb_seek(h, start);
-      while (h.pos > pn) {
-        const uint32_t e = tab[h.w >> (64 - mb)];
-        const int nb = (int)(e >> 8);
-        if (nb == 0) {  // not a table zstd builds: no progress possible
-          bad = 1;
-          break;
+    if (work && redo) {
+      const uint32_t cnt_old = cnt;
+      const int end_old = endpos;
+      cnt = 0;
+      endpos = start;
+      if (start > pn) {
+        hb_seek(h, start);
+        bool met = false;
+        if (round == 0) {
+          uint32_t limit = 16, jj = 0;
+          while (h.pos > pn) {
+            const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
+            const int nb = (int)(e >> 8);
+            if (nb == 0) {  // not a table zstd builds: no progress possible
+              bad = 1;
+              break;
+            }
+            cnt++;
+            hb_skip(h, nb);
+            if (cnt == limit) {
+              if (jj == 0) ck0 = h.pos;
+              else if (jj == 1) ck1 = h.pos;
+              else if (jj == 2) ck2 = h.pos;
+              else if (jj == 3) ck3 = h.pos;
+              jj++;
+              limit <<= 2;
+            }
+          }
+        } else {
+          // (marks are only trusted in round 1: later rounds -- rare -- decode their segment whole)
+          uint32_t jj = round == 1 ? 0u : 4u;
+          while (h.pos > pn) {
+            if (jj < 4) {
+              int ck = jj == 0 ? ck0 : (jj == 1 ? ck1 : (jj == 2 ? ck2 : ck3));
+              while (jj < 4 && h.pos < ck) {  // passed without standing on it (a mark never reached is -1: below everything)
+                jj++;
+                ck = jj == 1 ? ck1 : (jj == 2 ? ck2 : ck3);
+              }
+              if (jj < 4 && h.pos == ck) {
+                met = true;
+                break;
+              }
+            }
+            const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
+            const int nb = (int)(e >> 8);
+            if (nb == 0) {
+              bad = 1;
+              break;
+            }
+            cnt++;
+            hb_skip(h, nb);
+          }
+          if (met) {
+            cnt += cnt_old - (16u << (2 * jj));  // the old path had 16 * 4^jj symbols above this mark
+            endpos = end_old;
+          }
         }
-        cnt++;
-        h.w <<= nb;
-        h.pos -= nb;
-        h.avail -= nb;
-        if (h.avail < mb) hb_seek(h, h.pos);
+        if (!met) endpos = h.pos;
       }
-      endpos = h.pos;
     }
     // predecessor's crossing point -> this lane's start (lane 0 of a stream starts at the top)
     const int prev = __shfl_up(endpos, 1);
-    bool changed = false;
+    redo = false;
     if (k > 0 && work && prev != start) {
       start = prev;
-      changed = true;
+      redo = true;
     }
-    if (!__ballot(changed)) break;
+    if (!__ballot(redo)) break;
   }
   // symbols before this lane inside its stream
   uint32_t incl = cnt;
@@ -307,7 +383,7 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
     uint64_t acc = 0;
     hb_seek(h, start);
     while (h.pos > pn) {
-      const uint32_t e = tab[h.w >> (64 - mb)];
+      const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
       const int nb = (int)(e >> 8);
       acc |= (uint64_t)(e & 0xff) << (8 * nacc);
       if (++nacc == 8) {
@@ -316,10 +392,7 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
         nacc = 0;
         acc = 0;
       }
-      h.w <<= nb;
-      h.pos -= nb;
-      h.avail -= nb;
-      if (h.avail < mb) hb_seek(h, h.pos);
+      hb_skip(h, nb);
     }
     for (uint32_t t = 0; t < nacc; t++) out[i + t] = (uint8_t)(acc >> (8 * t));
   }

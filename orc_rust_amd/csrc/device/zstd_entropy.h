@@ -202,7 +202,8 @@ __device__ __forceinline__ long zfse_from_block(ZEntLds& L, ZFse* t, int* log_ou
 }
 
 // Huffman tree description at q (qn bytes available) -> L.h.huf; returns the bytes it takes or -1
-__device__ __forceinline__ long zhuf_tree(ZEntLds& L, const uint8_t* q, uint32_t qn, int* maxbits, uint32_t lane) {
+template <class LDS>
+__device__ __forceinline__ long zhuf_tree(LDS& L, const uint8_t* q, uint32_t qn, int* maxbits, uint32_t lane) {
   if (qn < 1) return -1;
   int nw;
   const uint32_t hb = q[0];
@@ -480,6 +481,59 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
   return P == 0 ? 0 : 24;  // every bit must be used
 }
 
+// The literals of one block (Huffman coded: lit_type 2, or 3 = Treeless) -> B.lit_out.  Returns 0 or a diagnostic code.
+// LDS: ZEntLds or ZLitLds (the same members; the latter without the room of the sequences phase).
+template <class LDS>
+__device__ __forceinline__ int zstd_literals_job(LDS& L, const ZBlock& B, const uint8_t* src, uint8_t* lit_out, uint32_t lane PROF_PARM) {
+  int st = 0;
+  int mb = 0;
+  PROF_MARK(0);
+  const uint8_t* q = src + B.content_off + B.lit_hdr;
+  uint32_t qn = B.lit_comp;
+  if (B.lit_type == 2) {
+    const long used = zhuf_tree(L, q, qn, &mb, lane);
+    if (used < 0) st = 11;
+    else {
+      q += used;
+      qn -= (uint32_t)used;
+    }
+  } else {
+    // Treeless: the table of the block that last described one (same frame)
+    if (zhuf_tree(L, src + B.huf_off, B.huf_end - B.huf_off, &mb, lane) < 0) st = 12;
+  }
+  PROF_MARK(1);
+  if (!st) {
+    int bad = 0;
+    const uint32_t regen = B.lit_regen;
+    if (B.lit_streams == 1) {
+      bad = huf_decode_par(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true);
+    } else {
+      if (qn < 6) st = 13;
+      else {
+        const uint32_t s1 = q[0] | (q[1] << 8), s2 = q[2] | (q[3] << 8), s3 = q[4] | (q[5] << 8);
+        if (6 + s1 + s2 + s3 > qn) st = 14;
+        else {
+          const uint32_t s4 = qn - 6 - s1 - s2 - s3;
+          const uint32_t seg = (regen + 3) / 4;
+          if (seg * 3 > regen) st = 15;
+          else {
+            const uint8_t* bp = q + 6;
+            const uint32_t k = lane >> 4;  // stream of this lane (16 lanes each)
+            const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
+            const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
+            const uint32_t on = k < 3 ? seg : regen - 3 * seg;
+            bad = huf_decode_par(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true);
+          }
+        }
+      }
+    }
+    if (!st && __ballot(bad != 0)) st = 16;
+  }
+  wave_sync();
+  PROF_MARK(2);
+  return st;
+}
+
 // ---- the kernel -------------------------------------------------------------------------------------------------
 // Two independent jobs per compressed block, each a workgroup of one wavefront: blockIdx.x < n_blocks decodes the
 // SEQUENCES of block blockIdx.x (the long serial chain: those workgroups come first), blockIdx.x >= n_blocks decodes the
@@ -505,53 +559,7 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
   uint32_t* dump = (uint32_t*)as_global((void*)dump_words) + (size_t)(b & 1023u) * 64;
   int st = 0;
   // ---- literals ----
-  if (lit_job && B.lit_type >= 2) {
-    int mb = 0;
-    PROF_MARK(0);
-    const uint8_t* q = src + B.content_off + B.lit_hdr;
-    uint32_t qn = B.lit_comp;
-    if (B.lit_type == 2) {
-      const long used = zhuf_tree(L, q, qn, &mb, lane);
-      if (used < 0) st = 11;
-      else {
-        q += used;
-        qn -= (uint32_t)used;
-      }
-    } else {
-      // Treeless: the table of the block that last described one (same frame)
-      if (zhuf_tree(L, src + B.huf_off, B.huf_end - B.huf_off, &mb, lane) < 0) st = 12;
-    }
-    PROF_MARK(1);
-    if (!st) {
-      int bad = 0;
-      const uint32_t regen = B.lit_regen;
-      if (B.lit_streams == 1) {
-        bad = huf_decode_par(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true);
-      } else {
-        if (qn < 6) st = 13;
-        else {
-          const uint32_t s1 = q[0] | (q[1] << 8), s2 = q[2] | (q[3] << 8), s3 = q[4] | (q[5] << 8);
-          if (6 + s1 + s2 + s3 > qn) st = 14;
-          else {
-            const uint32_t s4 = qn - 6 - s1 - s2 - s3;
-            const uint32_t seg = (regen + 3) / 4;
-            if (seg * 3 > regen) st = 15;
-            else {
-              const uint8_t* bp = q + 6;
-              const uint32_t k = lane >> 4;  // stream of this lane (16 lanes each)
-              const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
-              const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
-              const uint32_t on = k < 3 ? seg : regen - 3 * seg;
-              bad = huf_decode_par(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true);
-            }
-          }
-        }
-      }
-      if (!st && __ballot(bad != 0)) st = 16;
-    }
-    wave_sync();
-    PROF_MARK(2);
-  }
+  if (lit_job && B.lit_type >= 2) st = zstd_literals_job(L, B, src, lit_out, lane PROF_ARG);
   // ---- sequences ----
   if (!lit_job && B.nseq) {
     int ll_log = 0, of_log = 0, ml_log = 0;
@@ -586,6 +594,7 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
         h.pad = 0;
         *(ZSeqHdr*)as_global((void*)(zhdr + b)) = h;
       }
+      PROF_MARK(5);
       PROF_END_AT(112);
       return;
     }
@@ -603,6 +612,37 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
     __hip_atomic_store(&status_out[job], (uint32_t)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // jobs that have ended (progress[n_blocks] is the execution kernel's queue head): once all have, the workgroups of the
     // execution kernel beside this one stop taking chunks and leave the rest to a launch that may fill the machine
+    __hip_atomic_fetch_add(progress + n_blocks + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---- table scale: the literals as a kernel of their own (zstd_lanes.h runs the sequences) -------------------------------
+// The Huffman phase needs a third of the LDS of zstd_entropy_kernel (whose allocation is sized by the FSE tables of the sequences
+// phase): 28 wavefronts per CU instead of 10.  The decoder is a chain of table lookups per lane -- what it needs is wavefronts
+// to switch to.  Job j = the literals of block j; status_out[n_blocks + j] as zstd_entropy_kernel writes it.
+struct ZLitLds {
+  struct {
+    uint16_t huf[2048];  // sym | nb << 8
+    uint8_t weights[256];
+    FseEnt wt[64];
+  } h;
+  int16_t norm[256];
+  uint16_t next[256];
+};
+extern "C" __global__ void __launch_bounds__(64) zstd_literals_kernel(const ZBlock* __restrict__ blocks, uint32_t n_blocks, uint32_t* status_out, uint32_t* progress) {
+  __shared__ ZLitLds L;
+  const uint32_t b = blockIdx.x;
+  if (b >= n_blocks) return;
+  const uint32_t lane = threadIdx.x;
+  PROF_BEGIN();
+  const ZBlock& B = *glob(blocks + b);
+  int st = 0;
+  if (B.lit_type >= 2) st = zstd_literals_job(L, B, as_global(B.src), (uint8_t*)as_global((void*)B.lit_out), lane PROF_ARG);
+  PROF_END_AT(112);
+  // (as zstd_entropy_kernel ends a job: the execution kernel may be running beside the kernel that follows this one)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (lane == 0) {
+    __hip_atomic_store(&status_out[n_blocks + b], (uint32_t)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(progress + n_blocks + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

@@ -18,14 +18,6 @@
 // Output and status words are those of zstd_entropy_kernel; lz_exec_kernel runs behind this kernel.
 #pragma once
 
-// 64 stream bits from bit `wb` (a multiple of 8; may lie before the stream: those bits read as zero) of the stream at q
-__device__ __forceinline__ uint64_t zl_word(const uint8_t* q, int wb) {
-  const int bo = wb >> 3;
-  const uint64_t v = ld_u64(q + (bo < 0 ? 0 : bo));
-  const int neg = bo < 0 ? -bo : 0;  // bytes of the word that lie before the stream
-  return neg >= 8 ? 0ull : v << (8 * neg);
-}
-
 template <int NCH>
 __device__ __forceinline__ void zstd_seq_lanes(uint16_t* tabs, const ZBlock* blocks, uint32_t n_chains, const uint16_t* ztab_, const ZSeqHdr* zhdr_,
                                                uint32_t* status_out_) {
