@@ -42,6 +42,11 @@ import time
 
 import numpy as np
 
+# The decoder runs its column lanes, the literals kernel and the copies back on streams of their own; the HIP runtime maps streams
+# onto 4 hardware queues by default and kernels that share a queue run one after the other (measured: the Zstandard literals
+# kernel beside the sequences kernel only with more queues).  A setting of the runtime, read when it starts: INTEGRATION.md.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

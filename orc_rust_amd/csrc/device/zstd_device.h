@@ -101,14 +101,18 @@ __device__ __forceinline__ int fse_build_dev(FseEnt* t, const int16_t* norm, int
 }
 
 // FSE table description (forward bit stream); returns bytes consumed or -1.  Uniform.
+// `stg`: 128 bytes of LDS the description is read through (one load of the wavefront instead of a dependent memory access per byte).
 __device__ __forceinline__ long fse_read_ncount_dev(const uint8_t* p, uint32_t n, int16_t* norm, int* nsym_io, int* log_out, int maxlog,
-                                                    uint32_t lane) {
+                                                    uint32_t lane, uint8_t* stg) {
+  const uint32_t staged = n < 128u ? n : 128u;
+  if (lane < 32 && 4 * lane < staged) reinterpret_cast<uint32_t*>(stg)[lane] = ld_u32(p + 4 * lane);  // (up to 3 bytes behind the description: slack of the arena)
+  wave_sync();
   uint32_t pos = 0;
   uint64_t bb = 0;
   int bc = 0;
 #define ZNEED(k)                                  \
   while (bc < (k)) {                              \
-    uint64_t byte_ = pos < n ? p[pos] : 0;        \
+    uint64_t byte_ = pos < n ? (pos < staged ? stg[pos] : p[pos]) : 0; \
     if (pos >= n + 8) return -1;                  \
     pos++;                                        \
     bb |= byte_ << bc;                            \

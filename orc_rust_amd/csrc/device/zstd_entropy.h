@@ -75,61 +75,80 @@ struct ZEntLds {
   int16_t norm[256];
   uint16_t next[256];
   uint8_t sym[512];        // symbol of every cell while a table is being built
+  __attribute__((aligned(4))) uint8_t stage[128];  // a table description on its way from memory to the parser
 };
 
 // FSE decoding table with the symbol's extra bits and base value folded into every cell.  which: 0 LL, 1 OF, 2 ML.
-// Lane s works for symbol s (at most 53 symbols): the cells are spread over the table in closed form when no symbol has
-// the "less than one" probability (else by lane 0, cell after cell), then every lane walks the table once and numbers
-// the cells of its own symbol in ascending order -- the order that fixes each cell's next-state base (RFC 8878 4.1.1).
+// Lane s works for symbol s (at most 53 symbols).  The serial construction of RFC 8878 4.1.1 -- spread the symbols over the
+// table with a fixed stride, skipping the cells taken from the top by the "less than one" probabilities, then number the
+// cells of every symbol in ascending order -- is done by the whole wavefront:
+//   * the stride visits every cell once (it is odd): visit t goes to cell u(t) = t * step mod size.  With `high` the last
+//     cell below the low-probability ones, the j-th PLACED symbol lands in the j-th visit whose cell is <= high: a running
+//     count of such visits (ballot + popcount, 64 visits per turn) gives every visit its j, `expand[j]` its symbol;
+//   * cells are numbered 64 at a time in ascending order: for every distinct symbol among the 64 (a loop over ballots) a
+//     cell's number is the symbol's running count (kept in the symbol's lane) plus the cells of that symbol below it.
+// A table took ~80 us of a wavefront the serial way (tens of thousands of blocks per call: milliseconds), now a few.
 __device__ __forceinline__ int zfse_build(ZFse* t, uint8_t* symtab, const int16_t* norm, int nsym, int log, uint16_t* next, int which, uint32_t lane,
                                           uint16_t* ct = nullptr) {
-  const int size = 1 << log;
-  const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+  const uint32_t size = 1u << log;
+  const uint32_t step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
   const int cnt = (int)lane < nsym ? (int)norm[lane] : 0;
-  const bool lowprob = __ballot(cnt == -1) != 0;
-  int bad = 0;
-  if (!lowprob) {
-    const uint32_t c = cnt > 0 ? (uint32_t)cnt : 0u;
-    const uint32_t incl = wave_incl_scan_u32(c, lane);
-    if ((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) != (uint32_t)size) bad = 1;  // (the serial walk would not end on cell 0)
-    if (!bad)
-      for (uint32_t k = incl - c; k < incl; k++) symtab[(k * (uint32_t)step) & (uint32_t)mask] = (uint8_t)lane;
-  } else {
-    if (lane == 0) {
-      int high = size - 1;
-      for (int s = 0; s < nsym; s++)
-        if (norm[s] == -1) symtab[high--] = (uint8_t)s;
-      int pos = 0;
-      for (int s = 0; s < nsym; s++) {
-        for (int i = 0; i < norm[s]; i++) {
-          symtab[pos] = (uint8_t)s;
-          do {
-            pos = (pos + step) & mask;
-          } while (pos > high);
-        }
-      }
-      if (pos != 0) bad = 1;
-    }
-    bad = __shfl(bad, 0);
+  const bool low = cnt == -1;
+  const unsigned long long lowm = __ballot(low);
+  const unsigned long long below = (1ull << lane) - 1;
+  const uint32_t nlow = (uint32_t)__popcll(lowm);
+  const uint32_t c = cnt > 0 ? (uint32_t)cnt : 0u;
+  const uint32_t incl = wave_incl_scan_u32(c, lane);
+  if ((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) + nlow != size) return 1;  // (the serial walk would not end on cell 0)
+  const uint32_t high = size - 1 - nlow;
+  uint8_t* expand = reinterpret_cast<uint8_t*>(next);  // 512 bytes: the symbol of the j-th placed cell
+  if (low) symtab[size - 1 - (uint32_t)__popcll(lowm & below)] = (uint8_t)lane;
+  for (uint32_t k = incl - c; k < incl; k++) expand[k] = (uint8_t)lane;
+  wave_sync();
+  uint32_t placed = 0;
+  for (uint32_t t0 = 0; t0 < size; t0 += 64) {
+    const uint32_t tt = t0 + lane;
+    const uint32_t u = (tt * step) & mask;
+    const bool f = tt < size && u <= high;
+    const unsigned long long m = __ballot(f);
+    if (f) symtab[u] = expand[placed + (uint32_t)__popcll(m & below)];
+    placed += (uint32_t)__popcll(m);
   }
   wave_sync();
-  if (bad) return 1;
-  (void)next;
-  if ((int)lane < nsym && cnt != 0) {
-    uint32_t ns = cnt == -1 ? 1u : (uint32_t)cnt;
-    const uint8_t add = which == 0 ? Z_LL_BITS[lane] : (which == 1 ? (uint8_t)lane : Z_ML_BITS[lane]);
-    const uint32_t base = which == 0 ? Z_LL_BASE[lane] : (which == 1 ? 1u << lane : Z_ML_BASE[lane]);
-    for (int i = 0; i < size; i++) {
-      if (symtab[i] != lane) continue;
-      const int nb = log - z_hibit(ns);
+  // this lane's symbol: what its cells carry besides the state
+  const uint32_t my_add = which == 0 ? (lane < 36 ? Z_LL_BITS[lane] : 0u) : (which == 1 ? lane : (lane < 53 ? Z_ML_BITS[lane] : 0u));
+  const uint32_t my_base = which == 0 ? (lane < 36 ? Z_LL_BASE[lane] : 0u) : (which == 1 ? 1u << (lane & 31u) : (lane < 53 ? Z_ML_BASE[lane] : 0u));
+  uint32_t nxt = low ? 1u : c;  // next state number of symbol `lane`
+  for (uint32_t i0 = 0; i0 < size; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const bool valid = i < size;
+    const uint32_t s = valid ? (uint32_t)symtab[i] : 0xffu;
+    uint32_t ns = 0, add = 0, base = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int l0 = __builtin_ctzll(todo);
+      const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)s, l0);
+      const unsigned long long m = __ballot(valid && s == s0);
+      const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)s0);
+      const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)my_add, (int)s0);
+      const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)my_base, (int)s0);
+      if (valid && s == s0) {
+        ns = first + (uint32_t)__popcll(m & below);
+        add = a0;
+        base = b0;
+      }
+      if (lane == s0) nxt += (uint32_t)__popcll(m);
+      todo &= ~m;
+    }
+    if (valid) {
+      const int nb = log - z_hibit(ns | (ns == 0));
       ZFse e;
-      e.next = (uint16_t)((ns << nb) - (uint32_t)size);
+      e.next = (uint16_t)((ns << nb) - size);
       e.nb = (uint8_t)nb;
-      e.add = add;
+      e.add = (uint8_t)add;
       e.base = base;
       t[i] = e;
-      if (ct) ct[i] = (uint16_t)(lane | ns << 6);
-      ns++;
+      if (ct) ct[i] = (uint16_t)(s | ns << 6);
     }
   }
   wave_sync();
@@ -172,7 +191,7 @@ __device__ __forceinline__ long zfse_table(ZEntLds& L, ZFse* t, int* log_out, in
   }
   if (mode == 2) {
     int nsym = maxsym, log;
-    const long c = fse_read_ncount_dev(p, n, L.norm, &nsym, &log, maxlog, lane);
+    const long c = fse_read_ncount_dev(p, n, L.norm, &nsym, &log, maxlog, lane, L.stage);
     if (c < 0) return -1;
     if (build) {
       if (zfse_build(t, L.sym, L.norm, nsym, log, L.next, which, lane, ct)) return -1;
@@ -218,7 +237,7 @@ __device__ __forceinline__ long zhuf_tree(LDS& L, const uint8_t* q, uint32_t qn,
   } else {
     if (1 + hb > qn) return -1;
     int nsym = 256, log;
-    const long c = fse_read_ncount_dev(q + 1, hb, L.norm, &nsym, &log, 6, lane);
+    const long c = fse_read_ncount_dev(q + 1, hb, L.norm, &nsym, &log, 6, lane, L.stage);
     if (c < 0) return -1;
     if (fse_build_dev(L.h.wt, L.norm, nsym, log, L.next, lane)) return -1;
     RBits r;
@@ -628,6 +647,7 @@ struct ZLitLds {
   } h;
   int16_t norm[256];
   uint16_t next[256];
+  __attribute__((aligned(4))) uint8_t stage[128];
 };
 extern "C" __global__ void __launch_bounds__(64) zstd_literals_kernel(const ZBlock* __restrict__ blocks, uint32_t n_blocks, uint32_t* status_out, uint32_t* progress) {
   __shared__ ZLitLds L;
