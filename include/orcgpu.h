@@ -367,8 +367,10 @@ int orcgpu_last_timing(const orcgpu_ctx* ctx, float* total_ms, float* expand_ms,
  *   4 finishers (null spacing, strings, decimals, timestamps) + the summary copy
  *   5 (part of 0) the first stage of the block decompressors alone: Zstandard entropy decoding / Snappy and LZ4 token parsing;
  *     0 minus 5 = the LZ77 execution kernels (and DEFLATE, which is one kernel)
+ *   6 (part of 5) Zstandard at table scale, where the sequences are decoded one lane per block: what runs in front of that
+ *     kernel (the FSE table construction); 5 minus 6 = the sequences kernel (the literals kernel runs beside it).  0 otherwise
  * ms[0..n) receives the first n of them. */
-#define ORCGPU_N_PHASES 6
+#define ORCGPU_N_PHASES 7
 int orcgpu_last_phase_ms(const orcgpu_ctx* ctx, float* ms, uint32_t n);
 
 #ifdef __cplusplus

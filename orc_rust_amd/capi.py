@@ -269,12 +269,13 @@ class Context:
 
 
     PHASES = ("decompress", "walk", "present", "expand", "finish")  # + "decompress_stage1": the part of "decompress" spent in its first stage
+    # + "decompress_tables": the part of that in front of the Zstandard sequences kernel (one lane per block; 0 otherwise)
 
     def phase_ms(self):
         """Device milliseconds of the last decode call per pipeline phase (orcgpu_last_phase_ms)."""
-        a = (C.c_float * 6)()
-        self.L.orcgpu_last_phase_ms(self.h, a, 6)
-        return dict(zip(self.PHASES + ("decompress_stage1",), [float(x) for x in a]))
+        a = (C.c_float * 7)()
+        self.L.orcgpu_last_phase_ms(self.h, a, 7)
+        return dict(zip(self.PHASES + ("decompress_stage1", "decompress_tables"), [float(x) for x in a]))
 
 
 class Staged:

@@ -16,7 +16,7 @@
 //      per lane extract all fields at once from a wave-uniform 64-bit window.  The bit stream itself is
 //      held in a vector register (lane j = dword j of the current 256-byte segment), so the window is
 //      rebuilt with three v_readlane per sequence and no memory access sits on the chain.
-// It writes {offset value, match length, literal length} per sequence and one status word per block (0 = ok, else a
+// It writes offset value, match length and literal length per sequence (three arrays) and one status word per block (0 = ok, else a
 // diagnostic code: any nonzero value rejects the chunk); repeat offsets are resolved, and
 // the LZ77 copies executed, by lz_exec_kernel (lz_exec.h), one workgroup per chunk.
 #pragma once
@@ -24,7 +24,7 @@
 struct ZBlock {
   const uint8_t* src;    // chunk payload in the staged arena
   uint8_t* lit_out;      // decoded literals (lit_type >= 2): lit_regen bytes (+ 8 bytes of slack)
-  uint32_t* seq_out;     // nseq x {offset value, match length, literal length}
+  uint32_t* seq_out;     // three arrays of ((nseq + 3) & ~3) entries, one behind the other: offset values, match lengths, literal lengths
   uint32_t chunk;        // index into the chunk table
   uint32_t content_off, content_end;  // block content inside the payload
   uint32_t lit_type, lit_streams, lit_hdr, lit_regen, lit_comp;
@@ -371,6 +371,7 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
   // (agent scope, nothing stays dirty in this XCD's L2) and the count of sequences that have LANDED is published one flush
   // late -- by then the stores of the flush before have long been acknowledged, so the wait costs nothing.
   uint32_t published = 0;
+  const uint32_t np = (nseq + 3u) & ~3u;
   auto flush = [&](uint32_t first, uint32_t count) {  // sequences [first, first + count) are in seqbuf
     wave_sync();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -378,8 +379,13 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
       if (lane == 0) __hip_atomic_store(progress, first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       published = first;
     }
-    uint32_t* o = seq_out + 3ull * first;
-    for (uint32_t k = lane; k < 3 * count; k += 64) __hip_atomic_store(&o[k], sb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (three arrays of `np` entries: offset values, match lengths, literal lengths)
+    if (lane < count) {
+      uint32_t* o = seq_out + first + lane;
+      __hip_atomic_store(o, sb[3 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(o + np, sb[3 * lane + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(o + 2 * np, sb[3 * lane + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     wave_sync();
   };
   const uint32_t tbase = (uint32_t)(uintptr_t)tb;  // LDS byte address of this lane's table

@@ -1,30 +1,40 @@
-// zstd_lanes.h -- Zstandard sequences, ONE LANE PER COMPRESSED BLOCK (table scale).
+// zstd_lanes.h -- Zstandard sequences at table scale: FOUR LANES PER COMPRESSED BLOCK, sixteen blocks per wavefront.
 //
 // The FSE state chain of a block is serial (RFC 8878 3.1.1.3.2.1.1): one table lookup and one variable-length bit read
 // per sequence, each depending on the one before.  zstd_entropy.h gives a block a whole wavefront -- right when a call
 // holds few blocks (a stripe: the call lasts as long as its longest chain), wasteful when it holds tens of thousands (a
-// table: 8 of 64 lanes busy, the stage is bound by the instructions it issues per sequence).  Here every lane of a
-// wavefront follows a chain of its own, with ordinary per-lane code: the same instructions advance 64 blocks.
+// table: 8 of 64 lanes busy, the stage is bound by the instructions it issues per sequence).  Here the same instructions
+// advance 16 blocks:
 //
-//   * zstd_entropy_kernel (tables mode) builds the three FSE tables of every block as before and leaves them in memory as
-//     2-byte cells {symbol : 6, next-state number : 10}; the number of state bits and the base of the next state follow
-//     from the number (nb = log - floor(log2 n), next = (n << nb) - size), a symbol's extra bits and base value from two
-//     64-entry tables held in a vector register (ds_bpermute).  A block's tables are 2560 bytes: LL 512 + ML 512 + OF 256 cells.
-//   * zstd_seq_lanes_kernel: a wavefront loads the tables of its NCH chains into LDS (NCH x 2560 bytes: what bounds the chains
-//     in flight per CU is LDS, 64 of them), then every lane decodes its block's sequences: three 2-byte LDS reads, the six bit
-//     fields of a sequence cut out of a 64-bit window of the backward bit stream that the lane keeps in registers (128 bits
-//     + the next 8 bytes on their way: no memory access sits on the chain), 12 bytes stored per sequence.
+//   * zstd_entropy_kernel (tables mode) builds the three FSE tables of every block and leaves them in memory as 2-byte cells
+//     {symbol : 6, next-state number : 10}; the number of state bits and the base of the next state follow from the number
+//     (nb = log - floor(log2 n), next = (n << nb) - size), a symbol's extra bits and base value from 64-entry tables held in
+//     vector registers (ds_bpermute: lane s holds symbol s).  A block's tables are 2560 bytes: LL 512 + ML 512 + OF 256 cells.
+//   * zstd_seq_quads_kernel: a wavefront loads the tables of its 16 chains into LDS (40 KiB: what bounds the chains in flight
+//     is LDS -- 64 per CU, four wavefronts, one per SIMD).  A chain is a QUAD of lanes: lane 0 follows the offset table, 1 the
+//     match-length table, 2 the literal-length table (3 stands by as a second literal-length lane).  A lane reads one cell,
+//     decodes one state, cuts its own extra bits and its own state bits out of a 64-bit window of the backward bit stream and
+//     keeps its own value; the six field widths of a sequence reach the other lanes of the quad by DPP quad broadcasts.  Every
+//     lane keeps the bit window itself (128 bits in registers + the next 8 bytes on their way: no memory access on the chain).
+//   * Output: three arrays per block (offset values, match lengths, literal lengths), so that a lane's values are contiguous:
+//     eight steps are kept in registers and leave as two 16-byte stores.  That matters more than it looks: this target counts
+//     loads and stores in ONE in-order counter, so the wait for a refill's load is also a wait for every store before it --
+//     with a 4-byte store per step, stores and refill waits were half of a step's ~900 cycles (stamped, -DORC_PROF).
 // Blocks are dealt out in the order of their sequence counts (the host sorts them), so the chains of a wavefront end together.
-// Output and status words are those of zstd_entropy_kernel; lz_exec_kernel runs behind this kernel.
+// Status words are those of zstd_entropy_kernel; the execution kernel (lz_exec_wave_kernel) runs behind this kernel.
 #pragma once
 
-template <int NCH>
-__device__ __forceinline__ void zstd_seq_lanes(uint16_t* tabs, const ZBlock* blocks, uint32_t n_chains, const uint16_t* ztab_, const ZSeqHdr* zhdr_,
-                                               uint32_t* status_out_) {
+#define ZQ_BCAST(v, k) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (k) * 0x55, 0xf, 0xf, false))  // lane k of the quad
+#define ZQ_STEPS 8  // steps between stores
+
+extern "C" __global__ void __launch_bounds__(64) zstd_seq_quads_kernel(const ZBlock* __restrict__ blocks, uint32_t n_chains, const uint16_t* ztab_,
+                                                                      const ZSeqHdr* zhdr_, uint32_t* status_out_, uint32_t flags) {
+  // flags (timing experiments, ORCGPU_ZSTD_K2_EXTRA): 1 = no stores, 2 = no refill loads (garbage results, the same steps)
+  __shared__ __attribute__((aligned(16))) uint16_t tabs[16 * ZL_CELLS];
   const uint32_t lane = threadIdx.x;
-  const uint32_t first = blockIdx.x * NCH;
+  const uint32_t first = blockIdx.x * 16u;
   if (first >= n_chains) return;
-  const uint32_t nch = n_chains - first < (uint32_t)NCH ? n_chains - first : (uint32_t)NCH;
+  const uint32_t nch = n_chains - first < 16u ? n_chains - first : 16u;
   const uint16_t* ztab = glob(ztab_);
   const ZSeqHdr* zhdr = glob(zhdr_);
   uint32_t* status_out = glob(status_out_);
@@ -36,13 +46,13 @@ __device__ __forceinline__ void zstd_seq_lanes(uint16_t* tabs, const ZBlock* blo
     for (uint32_t k = lane; k < n16; k += 64) l[k] = g[k];
   }
   __syncthreads();
-  const bool has = lane < nch;
-  const uint32_t c = first + (has ? lane : 0u);  // (idle lanes follow lane 0's chain and store nothing)
+  const uint32_t cw = lane >> 2, r = lane & 3u;  // chain of the wavefront; role: 0 OF, 1 ML, 2 LL (3: LL again, stores nothing)
+  const bool has = cw < nch;
+  const uint32_t c = first + (has ? cw : 0u);    // (idle quads follow chain 0 and store nothing)
   const ZBlock* B = glob(blocks + c);
   const ZSeqHdr H = zhdr[c];
   const uint8_t* q = as_global(B->src) + H.bit_off;
   const uint32_t end = B->content_end;
-  uint32_t* so = (uint32_t*)as_global((void*)B->seq_out);
   int st = (int)H.status;
   uint32_t qn = 0;
   if (!st) {
@@ -57,25 +67,32 @@ __device__ __forceinline__ void zstd_seq_lanes(uint16_t* tabs, const ZBlock* blo
       if (lastb == 0) st = 21;
     }
   }
-  if (st) {  // nothing to follow: an empty stream of zeros keeps the lane harmless
+  if (st) {  // nothing to follow: a stream of its own keeps the lanes harmless
     qn = 8;
     lastb = 1;
   }
-  uint32_t nseq = has && !st ? B->nseq : 0u;
+  const uint32_t nseq_b = B->nseq;
+  uint32_t nseq = has && !st ? nseq_b : 0u;
+  // this lane's array of the block's output: offset values, match lengths, literal lengths, (nseq + 3 & ~3) entries each
+  uint32_t* so = (uint32_t*)as_global((void*)B->seq_out) + (size_t)(r < 3 ? r : 0u) * ((nseq_b + 3u) & ~3u);
   const uint32_t llog = H.logs & 0xffu, olog = (H.logs >> 8) & 0xffu, mlog = (H.logs >> 16) & 0xffu;
-  const uint32_t lsize = 1u << llog, osize = 1u << olog, msize = 1u << mlog;
-  // a symbol's extra bits and base value: lane s holds symbol s
-  const uint32_t llpack = lane < 36 ? (uint32_t)Z_LL_BITS[lane] | Z_LL_BASE[lane] << 8 : 0u;
-  const uint32_t mlpack = lane < 53 ? (uint32_t)Z_ML_BITS[lane] | Z_ML_BASE[lane] << 8 : 0u;
+  const uint32_t log = r == 0 ? olog : (r == 1 ? mlog : llog);
+  const uint32_t size = 1u << log, c0 = 31u - log;  // state bits of a cell = clz(its state number) - (31 - log)
+  // per symbol (lane s holds symbol s): the extra bits of the three alphabets in one register, the base values in two
+  const uint32_t bitsreg = (lane < 36 ? (uint32_t)Z_LL_BITS[lane] : 0u) | (lane < 53 ? (uint32_t)Z_ML_BITS[lane] << 8 : 0u) | (lane & 31u) << 16;
+  const uint32_t llbase = lane < 36 ? Z_LL_BASE[lane] : 0u, mlbase = lane < 53 ? Z_ML_BASE[lane] : 0u;
+  const uint32_t bsh = r == 0 ? 16u : (r == 1 ? 8u : 0u);
+  // this lane's share of the field positions: its extra bits end behind those of the roles below it, its state bits behind
+  // the extra bits of all and the state bits of the roles above it (the states follow each other LL, ML, OF)
+  const uint32_t mx1 = r >= 1 ? ~0u : 0u, mx2 = r >= 2 ? ~0u : 0u, ms1 = r <= 1 ? ~0u : 0u, ms0 = r == 0 ? ~0u : 0u;
 
-  // the bit stream is read from its last set bit downwards.  P = unread bits; lo = stream bits [wb64 - 64, wb64),
-  // hi = [wb64, wb64 + 64) (kept as hi << 1), nx = the word below lo, on its way; always 0 <= P - wb64 <= 63.
+  // The bit stream is read from its last set bit downwards.  P = unread bits; lo = stream bits [wb64 - 64, wb64),
+  // hi = [wb64, wb64 + 64) (kept as hi << 1), nx = the word below lo, on its way (kept as loaded, with the shift that zeroes
+  // what lies before the stream: nothing waits for the load before the refill after this one); always 0 <= P - wb64 <= 63.
   int P = (int)(qn - 1) * 8 + (31 - __builtin_clz(lastb));
   int wb64 = 8 * (int)qn - 64;
   uint64_t hi1 = zl_word(q, wb64) << 1;
   uint64_t lo = zl_word(q, wb64 - 64);
-  // (nx is kept as loaded, with the shift that zeroes what lies before the stream: nothing waits for the load before the
-  // refill after this one)
   uint64_t nx;
   uint32_t nxs;
   auto fetch = [&](int wb) {
@@ -89,7 +106,7 @@ __device__ __forceinline__ void zstd_seq_lanes(uint16_t* tabs, const ZBlock* blo
       hi1 = lo << 1;
       lo = nxs >= 64u ? 0ull : nx << nxs;
       wb64 -= 64;
-      fetch(wb64 - 128);
+      if (!(flags & 2u)) fetch(wb64 - 128);
     }
   };
   auto window = [&]() -> uint64_t {  // stream bits [P - 64, P), bit 63 = the next unread bit
@@ -99,15 +116,13 @@ __device__ __forceinline__ void zstd_seq_lanes(uint16_t* tabs, const ZBlock* blo
   // field of `cnt` bits (< 32) that ends `e` bits below the top of the window x (neg = -e: shifts take the low 6 bits)
   auto field = [](uint64_t x, uint32_t neg, uint32_t cnt) -> uint32_t { return (uint32_t)(x >> (neg & 63u)) & ~(~0u << cnt); };
 
-  const uint32_t tb = (has ? lane : 0u) * ZL_CELLS;
-  uint32_t sL, sO, sM;
+  const uint32_t tb = (has ? cw : 0u) * ZL_CELLS + (r == 0 ? ZL_OF : (r == 1 ? ZL_ML : ZL_LL));
+  uint32_t s;
   {
     // initial states: LL, OF, ML
     const uint64_t x = window();
-    const uint32_t n1 = 0u - llog, n2 = n1 - olog, n3 = n2 - mlog;
-    sL = field(x, n1, llog);
-    sO = field(x, n2, olog);
-    sM = field(x, n3, mlog);
+    const uint32_t e = r == 0 ? llog + olog : (r == 1 ? llog + olog + mlog : llog);
+    s = field(x, 0u - e, log);
     P -= (int)(llog + olog + mlog);
     if (P < 0 && !st) {
       st = 22;
@@ -123,70 +138,63 @@ __device__ __forceinline__ void zstd_seq_lanes(uint16_t* tabs, const ZBlock* blo
   maxn = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxn);
   int Pfin = nseq ? 1 : 0;  // unread bits behind the last sequence (must be none)
 
-  for (uint32_t i = 0; i < maxn; i++) {
-    const uint32_t cl = tabs[tb + ZL_LL + sL], cm = tabs[tb + ZL_ML + sM], co = tabs[tb + ZL_OF + sO];
-    const uint32_t symL = cl & 63u, symM = cm & 63u, symO = co & 63u;
-    const uint32_t nsL = cl >> 6, nsM = cm >> 6, nsO = co >> 6;
-    const uint32_t pkL = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(symL << 2), (int)llpack);
-    const uint32_t pkM = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(symM << 2), (int)mlpack);
-    // (a lane without a chain, or behind the end of its chain, goes on decoding whatever it finds: its loads stay inside its
-    // stream, its states inside its tables, it stores nothing)
-    uint32_t nbL = llog - (31u - (uint32_t)__builtin_clz(nsL));
-    uint32_t nbM = mlog - (31u - (uint32_t)__builtin_clz(nsM));
-    uint32_t nbO = olog - (31u - (uint32_t)__builtin_clz(nsO));
-    const uint32_t nextL = (nsL << (nbL & 31u)) - lsize, nextM = (nsM << (nbM & 31u)) - msize, nextO = (nsO << (nbO & 31u)) - osize;
-    const bool last = i + 1 == nseq;
-    if (last) nbL = nbM = nbO = 0;  // no state update behind the last sequence
-    const uint32_t ofb = symO & 31u, mlb = pkM & 31u, llb = pkL & 31u;
-    // the fields follow each other downwards: offset, match length, literal length extra bits, then LL, ML, OF state bits
-    const uint32_t n1 = 0u - ofb, n2 = n1 - mlb, n3 = n2 - llb, n4 = n3 - nbL, n5 = n4 - nbM, n6 = n5 - nbO;
-    const uint32_t total = 0u - n6;
-    uint32_t ofx, mlx, llx, v4, v5, v6;
-    if (__builtin_expect(total > 64u, 0)) {
-      // more than 64 bits in one sequence (offsets / lengths near the format's limits): the extra bits (at most 63), then the states
-      uint64_t x = window();
-      ofx = field(x, n1, ofb);
-      mlx = field(x, n2, mlb);
-      llx = field(x, n3, llb);
-      P -= (int)(0u - n3);
+  // (a quad without a chain, or behind the end of its chain, goes on decoding whatever it finds: its loads stay inside its
+  // stream, reads beyond the LDS allocation return zero, it stores nothing)
+  for (uint32_t i0 = 0; i0 < maxn; i0 += ZQ_STEPS) {
+    uint32_t val[ZQ_STEPS];
+#pragma unroll
+    for (int k = 0; k < ZQ_STEPS; k++) {
+      const uint32_t i = i0 + (uint32_t)k;
+      const uint32_t cell = tabs[tb + s];
+      const uint32_t sym = cell & 63u, ns = cell >> 6;
+      const uint32_t bp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sym << 2), (int)bitsreg);
+      const uint32_t bl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sym << 2), (int)llbase);
+      const uint32_t bm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sym << 2), (int)mlbase);
+      const uint32_t nb = (uint32_t)__builtin_clz(ns) - c0;
+      const uint32_t next = (ns << (nb & 31u)) - size;
+      const uint32_t xb = (bp >> bsh) & 31u;
+      // the widths of the quad's six fields: they follow each other downwards -- offset, match length, literal length extra
+      // bits, then LL, ML, OF state bits
+      const uint32_t b0 = ZQ_BCAST(xb, 0), b1 = ZQ_BCAST(xb, 1), b2 = ZQ_BCAST(xb, 2);
+      const uint32_t n0 = ZQ_BCAST(nb, 0), n1 = ZQ_BCAST(nb, 1), n2 = ZQ_BCAST(nb, 2);
+      const uint32_t e3 = b0 + b1 + b2;
+      const uint32_t xend = b0 + (b1 & mx1) + (b2 & mx2);
+      const uint32_t send = n2 + (n1 & ms1) + (n0 & ms0);  // (counted from behind the extra bits)
+      const uint32_t total = e3 + n0 + n1 + n2;
+      // behind the last sequence no state is read: what must be left then is what its extra bits leave (the lanes read on)
+      if (i + 1 == nseq) Pfin = P - (int)e3;
+      uint32_t xv, sv;
+      if (__builtin_expect(total > 64u, 0)) {
+        // more than 64 bits in one sequence (offsets / lengths near the format's limits): the extra bits (at most 63), then the states
+        uint64_t x = window();
+        xv = field(x, 0u - xend, xb);
+        P -= (int)e3;
+        refill();
+        x = window();
+        sv = field(x, 0u - send, nb);
+        P -= (int)(total - e3);
+      } else {
+        const uint64_t x = window();
+        xv = field(x, 0u - xend, xb);
+        sv = field(x, 0u - (e3 + send), nb);
+        P -= (int)total;
+      }
       refill();
-      x = window();
-      const uint32_t m4 = 0u - nbL, m5 = m4 - nbM, m6 = m5 - nbO;
-      v4 = field(x, m4, nbL);
-      v5 = field(x, m5, nbM);
-      v6 = field(x, m6, nbO);
-      P -= (int)(0u - m6);
-    } else {
-      const uint64_t x = window();
-      ofx = field(x, n1, ofb);
-      mlx = field(x, n2, mlb);
-      llx = field(x, n3, llb);
-      v4 = field(x, n4, nbL);
-      v5 = field(x, n5, nbM);
-      v6 = field(x, n6, nbO);
-      P -= (int)total;
+      val[k] = (r == 0 ? 1u << (sym & 31u) : (r == 1 ? bm : bl)) + xv;
+      s = next + sv;
     }
-    refill();
-    if (i < nseq) {
-      so[0] = (1u << ofb) + ofx;
-      so[1] = (pkM >> 8) + mlx;
-      so[2] = (pkL >> 8) + llx;
+    if (r < 3 && i0 < nseq && !(flags & 1u)) {
+      if (i0 + ZQ_STEPS <= nseq) {
+        uint4* o = reinterpret_cast<uint4*>(so + i0);
+        o[0] = make_uint4(val[0], val[1], val[2], val[3]);
+        o[1] = make_uint4(val[4], val[5], val[6], val[7]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < ZQ_STEPS; k++)
+          if (i0 + (uint32_t)k < nseq) so[i0 + (uint32_t)k] = val[k];
+      }
     }
-    so += 3;
-    if (last) Pfin = P;
-    sL = (nextL + v4) & 511u;
-    sM = (nextM + v5) & 511u;
-    sO = (nextO + v6) & 255u;
   }
   if (!st && Pfin != 0) st = Pfin < 0 ? 23 : 24;  // the stream ran dry / every bit must be used
-  if (has) status_out[c] = (uint32_t)st;
+  if (has && r == 0 && !flags) status_out[c] = (uint32_t)st;
 }
-
-#define ZL_KERNEL(NAME, NCH)                                                                                                                  \
-  extern "C" __global__ void __launch_bounds__(64) NAME(const ZBlock* __restrict__ blocks, uint32_t n_chains, const uint16_t* ztab,          \
-                                                        const ZSeqHdr* zhdr, uint32_t* status_out) {                                          \
-    __shared__ __attribute__((aligned(16))) uint16_t tabs[NCH * ZL_CELLS];                                                                    \
-    zstd_seq_lanes<NCH>(tabs, blocks, n_chains, ztab, zhdr, status_out);                                                                      \
-  }
-ZL_KERNEL(zstd_seq_lanes64_kernel, 64)
-ZL_KERNEL(zstd_seq_lanes16_kernel, 16)

@@ -243,12 +243,12 @@ struct orcgpu_ctx {
   size_t pinned_cap = 0;
   uint8_t* fin_pinned = nullptr;       // staging of the finishers' job table
   size_t fin_pinned_cap = 0;
-  hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk, after the decompressors' first stage
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk, after the decompressors' first stage, in front of the Zstandard sequences kernel (one lane per block)
   uint32_t n_cus = 0;
   hipStream_t aux_stream = nullptr;   // the Zstandard execution kernel runs here, beside the entropy kernel on `stream`
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
   float last_total_ms = 0, last_expand_ms = 0;
-  float last_phase_ms[ORCGPU_N_PHASES] = {0, 0, 0, 0, 0, 0};
+  float last_phase_ms[ORCGPU_N_PHASES] = {0, 0, 0, 0, 0, 0, 0};
   uint32_t last_expand_launches = 0;
   // ---- staging pipeline (lane 0 only): a copy stream, two pinned pieces filled by a few host threads while the other one
   // is on its way to HBM, a pool of stripe arenas ----

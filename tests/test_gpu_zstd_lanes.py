@@ -1,9 +1,10 @@
-"""GPU parity, Zstandard sequences one LANE per block (device/zstd_lanes.h).  The library takes that path by itself only
-for calls with tens of millions of sequences (bench.py's table); ORCGPU_ZSTD_LANES=1 forces it, so the same inputs the
-wavefront-per-block kernel is tested with go through it here: real encoder output over the ten data shapes at three
-block sizes (one chain .. 600 chains per call, ragged last wavefront), lineitem stripes against the oracle and the
-generator's expectations, and the differential fuzz (valid and corrupted Zstandard stripes: same failing batch, same
-error kind as the oracle).  Both wavefront shapes (16 and 64 chains) run."""
+"""GPU parity, Zstandard at table scale (device/zstd_lanes.h: sequences by four lanes per block, sixteen blocks per
+wavefront; zstd_literals_kernel; lz_exec_wave_kernel).  The library takes that path by itself only for calls with tens of
+millions of sequences (bench.py's table); ORCGPU_ZSTD_LANES=1 forces it, so the same inputs the wavefront-per-block
+kernels are tested with go through it here: real encoder output over the ten data shapes at three block sizes (one
+chain .. 600 chains per call, ragged last wavefront, blocks with fewer than eight sequences), lineitem stripes against
+the oracle and the generator's expectations, and the differential fuzz (valid and corrupted Zstandard stripes: same
+failing batch, same error kind as the oracle)."""
 import numpy as np
 import pytest
 
@@ -15,10 +16,11 @@ from test_gpu_codecs import CODECS, DATA, DOUBLE, frame, shapes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["16", "64"])
+@pytest.fixture(params=["beside", "in front"])
 def lanes(request, monkeypatch):
+    """The table-scale path forced on; the literals kernel beside the sequences kernel (second stream) or in front of it."""
     monkeypatch.setenv("ORCGPU_ZSTD_LANES", "1")
-    monkeypatch.setenv("ORCGPU_ZSTD_LANES_NCH", request.param)
+    monkeypatch.setenv("ORCGPU_ZSTD_LIT_ASIDE", "1" if request.param == "beside" else "0")
     return request.param
 
 
