@@ -10,27 +10,34 @@
 //     {symbol : 6, next-state number : 10}; the number of state bits and the base of the next state follow from the number
 //     (nb = log - floor(log2 n), next = (n << nb) - size), a symbol's extra bits and base value from 64-entry tables held in
 //     vector registers (ds_bpermute: lane s holds symbol s).  A block's tables are 2560 bytes: LL 512 + ML 512 + OF 256 cells.
-//   * zstd_seq_quads_kernel: a wavefront loads the tables of its 16 chains into LDS (40 KiB: what bounds the chains in flight
-//     is LDS -- 64 per CU, four wavefronts, one per SIMD).  A chain is a QUAD of lanes: lane 0 follows the offset table, 1 the
-//     match-length table, 2 the literal-length table (3 stands by as a second literal-length lane).  A lane reads one cell,
-//     decodes one state, cuts its own extra bits and its own state bits out of a 64-bit window of the backward bit stream and
-//     keeps its own value; the six field widths of a sequence reach the other lanes of the quad by DPP quad broadcasts.  Every
-//     lane keeps the bit window itself (128 bits in registers + the next 8 bytes on their way: no memory access on the chain).
-//   * Output: three arrays per block (offset values, match lengths, literal lengths), so that a lane's values are contiguous:
-//     eight steps are kept in registers and leave as two 16-byte stores.  That matters more than it looks: this target counts
-//     loads and stores in ONE in-order counter, so the wait for a refill's load is also a wait for every store before it --
-//     with a 4-byte store per step, stores and refill waits were half of a step's ~900 cycles (stamped, -DORC_PROF).
+//   * zstd_seq_quads_kernel: a wavefront loads the tables of its 16 chains into LDS (40 KiB).  A chain is a QUAD of lanes: lane 0
+//     follows the offset table, 1 the match-length table, 2 the literal-length table (3 stands by as a second literal-length
+//     lane).  A lane reads one cell, decodes one state, cuts its own extra bits and its own state bits out of a 64-bit window
+//     of the backward bit stream and keeps its own value; the six field widths of a sequence reach the other lanes of the quad
+//     by DPP quad broadcasts.
+//   * The bit stream comes through a 256-byte RING per chain in LDS.  This target counts loads and stores in ONE in-order
+//     counter per wavefront: with 16 chains refilling their windows from memory whenever they ran low, some chain did so in
+//     nearly every step and every such wait was for the load issued a step before -- loads cost 10 of the kernel's 18 ms,
+//     stores 5 (measured by launching it again without them).  Now memory is touched every EIGHT steps, by all lanes at
+//     once: a quad fetches the next 64 bytes of its stream (16 per lane) into registers, writes the block fetched eight
+//     steps earlier into its ring, and stores the eight values each lane has collected (three arrays per block -- offset
+//     values, match lengths, literal lengths --, so a lane's values are contiguous: two 16-byte stores).  A step reads its
+//     window from the ring (one unaligned 8-byte LDS read, beside the cell read).
+// LDS per wavefront: 16 x (2560 + 272) bytes: three wavefronts (48 chains) per CU.
 // Blocks are dealt out in the order of their sequence counts (the host sorts them), so the chains of a wavefront end together.
 // Status words are those of zstd_entropy_kernel; the execution kernel (lz_exec_wave_kernel) runs behind this kernel.
 #pragma once
 
 #define ZQ_BCAST(v, k) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (k) * 0x55, 0xf, 0xf, false))  // lane k of the quad
-#define ZQ_STEPS 8  // steps between stores
+#define ZQ_STEPS 8  // steps between two visits to memory
+#define ZQ_RING 256        // bytes of a chain's stream held in LDS: stream byte b lives at ring[b & 255]
+#define ZQ_RING_BYTES 272  // (+ the first 8 bytes again behind the end: a window may start at 255; 16-byte aligned)
 
 extern "C" __global__ void __launch_bounds__(64) zstd_seq_quads_kernel(const ZBlock* __restrict__ blocks, uint32_t n_chains, const uint16_t* ztab_,
                                                                       const ZSeqHdr* zhdr_, uint32_t* status_out_, uint32_t flags) {
   // flags (timing experiments, ORCGPU_ZSTD_K2_EXTRA): 1 = no stores, 2 = no refill loads (garbage results, the same steps)
   __shared__ __attribute__((aligned(16))) uint16_t tabs[16 * ZL_CELLS];
+  __shared__ __attribute__((aligned(16))) uint8_t rings[16 * ZQ_RING_BYTES];
   const uint32_t lane = threadIdx.x;
   const uint32_t first = blockIdx.x * 16u;
   if (first >= n_chains) return;
@@ -86,49 +93,54 @@ extern "C" __global__ void __launch_bounds__(64) zstd_seq_quads_kernel(const ZBl
   // the extra bits of all and the state bits of the roles above it (the states follow each other LL, ML, OF)
   const uint32_t mx1 = r >= 1 ? ~0u : 0u, mx2 = r >= 2 ? ~0u : 0u, ms1 = r <= 1 ? ~0u : 0u, ms0 = r == 0 ? ~0u : 0u;
 
-  // The bit stream is read from its last set bit downwards.  P = unread bits; lo = stream bits [wb64 - 64, wb64),
-  // hi = [wb64, wb64 + 64) (kept as hi << 1), nx = the word below lo, on its way (kept as loaded, with the shift that zeroes
-  // what lies before the stream: nothing waits for the load before the refill after this one); always 0 <= P - wb64 <= 63.
+  // The bit stream is read from its last set bit downwards; P = unread bits.  Stream bytes [fill, fill + 256) are in the quad's
+  // ring (bytes before the stream are zeros); lane r of the quad moves bytes [16 r, 16 r + 16) of every 64-byte block.
   int P = (int)(qn - 1) * 8 + (31 - __builtin_clz(lastb));
-  int wb64 = 8 * (int)qn - 64;
-  uint64_t hi1 = zl_word(q, wb64) << 1;
-  uint64_t lo = zl_word(q, wb64 - 64);
-  uint64_t nx;
-  uint32_t nxs;
-  auto fetch = [&](int wb) {
-    const int bo = wb >> 3;
-    nx = ld_u64(q + (bo < 0 ? 0 : bo));
-    nxs = bo < 0 ? (uint32_t)(-bo) * 8u : 0u;
-  };
-  fetch(wb64 - 128);
-  auto refill = [&]() {
-    if (P < wb64) {
-      hi1 = lo << 1;
-      lo = nxs >= 64u ? 0ull : nx << nxs;
-      wb64 -= 64;
-      if (!(flags & 2u)) fetch(wb64 - 128);
+  uint8_t* const rg = rings + cw * ZQ_RING_BYTES;
+  auto load16 = [&](int b0) -> uint4 {  // stream bytes [b0, b0 + 16): zeros outside the stream (at most 15 bytes behind it are read: slack of the arena)
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (b0 >= 0 && (uint32_t)b0 < qn && !(flags & 2u)) {
+      const uint64_t a = ld_u64(q + b0), b = ld_u64(q + b0 + 8);
+      v = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
     }
+    return v;
   };
-  auto window = [&]() -> uint64_t {  // stream bits [P - 64, P), bit 63 = the next unread bit
-    const uint32_t s = (uint32_t)(P - wb64);
-    return (lo >> s) | (hi1 << (63u - s));
+  auto ring_put = [&](int b0, uint4 v) {
+    const uint32_t o = (uint32_t)b0 & (ZQ_RING - 1u);
+    *reinterpret_cast<uint4*>(rg + o) = v;
+    if (o == 0) *reinterpret_cast<uint2*>(rg + ZQ_RING) = make_uint2(v.x, v.y);
   };
-  // field of `cnt` bits (< 32) that ends `e` bits below the top of the window x (neg = -e: shifts take the low 6 bits)
-  auto field = [](uint64_t x, uint32_t neg, uint32_t cnt) -> uint32_t { return (uint32_t)(x >> (neg & 63u)) & ~(~0u << cnt); };
+  int fill = (((int)qn - 1) & ~63) + 64;  // (nothing yet: the block that holds the last byte comes first)
+  for (int k = 0; k < 4; k++) {
+    fill -= 64;
+    ring_put(fill + 16 * (int)r, load16(fill + 16 * (int)r));
+  }
+  lds_order();
+  uint4 pend = make_uint4(0, 0, 0, 0);
+  bool pending = false;
+  // the 64 bits that end 57..64 bits above... the word that holds stream bits [8 B, 8 B + 64), B = (top - 57) >> 3: at least 57 bits below `top`
+  auto window_at = [&](int top, int& t8) -> uint64_t {
+    const int B = (top - 57) >> 3;
+    t8 = top - 8 * B;
+    uint64_t w;
+    __builtin_memcpy(&w, rg + ((uint32_t)B & (ZQ_RING - 1u)), 8);
+    return w;
+  };
+  auto mask = [](uint32_t cnt) -> uint32_t { return ~(~0u << (cnt & 31u)); };
 
   const uint32_t tb = (has ? cw : 0u) * ZL_CELLS + (r == 0 ? ZL_OF : (r == 1 ? ZL_ML : ZL_LL));
   uint32_t s;
   {
-    // initial states: LL, OF, ML
-    const uint64_t x = window();
+    // initial states: LL, OF, ML (at most 26 bits)
+    int t8;
+    const uint64_t x = window_at(P, t8);
     const uint32_t e = r == 0 ? llog + olog : (r == 1 ? llog + olog + mlog : llog);
-    s = field(x, 0u - e, log);
+    s = (uint32_t)(x >> ((uint32_t)t8 - e)) & mask(log);
     P -= (int)(llog + olog + mlog);
     if (P < 0 && !st) {
       st = 22;
       nseq = 0;
     }
-    refill();
   }
   uint32_t maxn = nseq;
   for (int o = 32; o; o >>= 1) {
@@ -138,14 +150,34 @@ extern "C" __global__ void __launch_bounds__(64) zstd_seq_quads_kernel(const ZBl
   maxn = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxn);
   int Pfin = nseq ? 1 : 0;  // unread bits behind the last sequence (must be none)
 
-  // (a quad without a chain, or behind the end of its chain, goes on decoding whatever it finds: its loads stay inside its
-  // stream, reads beyond the LDS allocation return zero, it stores nothing)
+  // (a quad without a chain, or behind the end of its chain, goes on decoding whatever it finds in its ring and stores nothing)
   for (uint32_t i0 = 0; i0 < maxn; i0 += ZQ_STEPS) {
+    // ---- memory: every lane at once.  The block fetched a visit ago goes into the ring; the next one is fetched when the
+    // ring has room for it (its top 64 bytes are no longer needed).  Eight steps take 89 bytes at the very most: a quad that
+    // would have fewer than 104 below its cursor fetches at once (never seen with real data: a step takes ~2.5 bytes).
+    if (i0 < nseq) {
+      if (pending) {
+        fill -= 64;
+        ring_put(fill + 16 * (int)r, pend);
+        pending = false;
+      }
+      while ((P >> 3) - fill < 104) {
+        fill -= 64;
+        ring_put(fill + 16 * (int)r, load16(fill + 16 * (int)r));
+      }
+      if ((P >> 3) - fill < 190) {
+        pend = load16(fill - 64 + 16 * (int)r);
+        pending = true;
+      }
+    }
+    lds_order();
     uint32_t val[ZQ_STEPS];
 #pragma unroll
     for (int k = 0; k < ZQ_STEPS; k++) {
       const uint32_t i = i0 + (uint32_t)k;
       const uint32_t cell = tabs[tb + s];
+      int t8;
+      const uint64_t x = window_at(P, t8);
       const uint32_t sym = cell & 63u, ns = cell >> 6;
       const uint32_t bp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sym << 2), (int)bitsreg);
       const uint32_t bl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sym << 2), (int)llbase);
@@ -159,27 +191,23 @@ extern "C" __global__ void __launch_bounds__(64) zstd_seq_quads_kernel(const ZBl
       const uint32_t n0 = ZQ_BCAST(nb, 0), n1 = ZQ_BCAST(nb, 1), n2 = ZQ_BCAST(nb, 2);
       const uint32_t e3 = b0 + b1 + b2;
       const uint32_t xend = b0 + (b1 & mx1) + (b2 & mx2);
-      const uint32_t send = n2 + (n1 & ms1) + (n0 & ms0);  // (counted from behind the extra bits)
+      const uint32_t send = e3 + n2 + (n1 & ms1) + (n0 & ms0);
       const uint32_t total = e3 + n0 + n1 + n2;
       // behind the last sequence no state is read: what must be left then is what its extra bits leave (the lanes read on)
       if (i + 1 == nseq) Pfin = P - (int)e3;
       uint32_t xv, sv;
-      if (__builtin_expect(total > 64u, 0)) {
-        // more than 64 bits in one sequence (offsets / lengths near the format's limits): the extra bits (at most 63), then the states
-        uint64_t x = window();
-        xv = field(x, 0u - xend, xb);
-        P -= (int)e3;
-        refill();
-        x = window();
-        sv = field(x, 0u - send, nb);
-        P -= (int)(total - e3);
+      if (__builtin_expect(total <= 57u, 1)) {
+        xv = (uint32_t)(x >> ((uint32_t)t8 - xend)) & mask(xb);
+        sv = (uint32_t)(x >> ((uint32_t)t8 - send)) & mask(nb);
       } else {
-        const uint64_t x = window();
-        xv = field(x, 0u - xend, xb);
-        sv = field(x, 0u - (e3 + send), nb);
-        P -= (int)total;
+        // more bits than the window surely holds (offsets / lengths near the format's limits): a window per field
+        int u8;
+        const uint64_t x1 = window_at(P - (int)(xend - xb), u8);
+        xv = (uint32_t)(x1 >> ((uint32_t)u8 - xb)) & mask(xb);
+        const uint64_t x2 = window_at(P - (int)(send - nb), u8);
+        sv = (uint32_t)(x2 >> ((uint32_t)u8 - nb)) & mask(nb);
       }
-      refill();
+      P -= (int)total;
       val[k] = (r == 0 ? 1u << (sym & 31u) : (r == 1 ? bm : bl)) + xv;
       s = next + sv;
     }
