@@ -85,10 +85,9 @@ extern "C" __global__ void __launch_bounds__(64) zstd_seq_quads_kernel(const ZBl
   const uint32_t llog = H.logs & 0xffu, olog = (H.logs >> 8) & 0xffu, mlog = (H.logs >> 16) & 0xffu;
   const uint32_t log = r == 0 ? olog : (r == 1 ? mlog : llog);
   const uint32_t size = 1u << log, c0 = 31u - log;  // state bits of a cell = clz(its state number) - (31 - log)
-  // per symbol (lane s holds symbol s): the extra bits of the three alphabets in one register, the base values in two
-  const uint32_t bitsreg = (lane < 36 ? (uint32_t)Z_LL_BITS[lane] : 0u) | (lane < 53 ? (uint32_t)Z_ML_BITS[lane] << 8 : 0u) | (lane & 31u) << 16;
+  // base values per symbol: lane s holds symbol s (read by ds_bpermute, off the chain)
+  const uint32_t cA = r == 1 ? 32u : 16u, cC = r == 1 ? 43u : 25u, cD = r == 1 ? 36u : 19u;  // (extra bits of a length code: see the loop)
   const uint32_t llbase = lane < 36 ? Z_LL_BASE[lane] : 0u, mlbase = lane < 53 ? Z_ML_BASE[lane] : 0u;
-  const uint32_t bsh = r == 0 ? 16u : (r == 1 ? 8u : 0u);
   // this lane's share of the field positions: its extra bits end behind those of the roles below it, its state bits behind
   // the extra bits of all and the state bits of the roles above it (the states follow each other LL, ML, OF)
   const uint32_t mx1 = r >= 1 ? ~0u : 0u, mx2 = r >= 2 ? ~0u : 0u, ms1 = r <= 1 ? ~0u : 0u, ms0 = r == 0 ? ~0u : 0u;
@@ -179,12 +178,17 @@ extern "C" __global__ void __launch_bounds__(64) zstd_seq_quads_kernel(const ZBl
       int t8;
       const uint64_t x = window_at(P, t8);
       const uint32_t sym = cell & 63u, ns = cell >> 6;
-      const uint32_t bp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sym << 2), (int)bitsreg);
       const uint32_t bl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sym << 2), (int)llbase);
       const uint32_t bm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sym << 2), (int)mlbase);
       const uint32_t nb = (uint32_t)__builtin_clz(ns) - c0;
       const uint32_t next = (ns << (nb & 31u)) - size;
-      const uint32_t xb = (bp >> bsh) & 31u;
+      // extra bits of the symbol, by arithmetic (a table lookup here would be a second LDS round trip on the chain): offset codes
+      // are their own count; length codes below A have none, up to C they have max(1, (code - A) / 2), from there on code - D
+      // (LL: A 16, C 25, D 19; ML: A 32, C 43, D 36 -- RFC 8878 3.1.1.3.2.1.1)
+      const int tA = (int)sym - (int)cA;
+      const uint32_t half = (uint32_t)(tA >> 1) > 1u ? (uint32_t)(tA >> 1) : 1u;
+      const uint32_t lenb = tA < 0 ? 0u : (sym < cC ? half : sym - cD);
+      const uint32_t xb = (r == 0 ? sym : lenb) & 31u;
       // the widths of the quad's six fields: they follow each other downwards -- offset, match length, literal length extra
       // bits, then LL, ML, OF state bits
       const uint32_t b0 = ZQ_BCAST(xb, 0), b1 = ZQ_BCAST(xb, 1), b2 = ZQ_BCAST(xb, 2);
