@@ -557,9 +557,10 @@ uint32_t type_width(int t) {
 bool is_string_type(int t) { return t == ORCGPU_T_STRING || t == ORCGPU_T_VARCHAR || t == ORCGPU_T_CHAR || t == ORCGPU_T_BINARY; }
 
 // ---- per-call plan ------------------------------------------------------------------------------
-// (JC_PRESENT1..3: PRESENT streams of the fields of Structs, by depth: they are as long as their parent has non-null rows)
-enum JobClass { JC_PRESENT = 0, JC_RLE2 = 1, JC_RLE1 = 2, JC_BYTE = 3, JC_PRESENT1 = 4, JC_PRESENT2 = 5, JC_PRESENT3 = 6, JC_COUNT = 7 };
-constexpr int kMaxStructDepth = 3;
+// (JC_PRESENT1 + d - 1: PRESENT streams of the fields of Structs / arms of Unions at depth d: they are as long as their parent has non-null rows)
+// kMaxStructDepth classes of them: as deep as the file reader follows a type tree (reader_build: 8 levels below a root column)
+constexpr int kMaxStructDepth = 8;
+enum JobClass { JC_PRESENT = 0, JC_RLE2 = 1, JC_RLE1 = 2, JC_BYTE = 3, JC_PRESENT1 = 4, JC_COUNT = JC_PRESENT1 + kMaxStructDepth };
 
 struct JobPlan {
   int cls;

@@ -111,6 +111,29 @@ def test_row_selection_over_struct_columns(tmp_path):
         assert got.column(name).combine_chunks().equals(exp.column(name).combine_chunks()), name
 
 
+def test_structs_nested_six_deep(tmp_path):
+    """struct_decoder.rs builds field decoders recursively, to any depth; here the PRESENT phase runs once per depth (eight
+    levels: as far as the reader follows a type tree).  Nulls at every level, a string and a List at the bottom."""
+    n = 20_000
+    rng = np.random.default_rng(21)
+    def level(depth):
+        if depth == 6:
+            return {"v": int(rng.integers(-1000, 1000)) if rng.random() > 0.1 else None, "s": "x" * int(rng.integers(0, 5)),
+                    "l": None if rng.random() < 0.1 else [int(rng.integers(0, 9)) for _ in range(int(rng.integers(0, 3)))]}
+        return None if rng.random() < 0.12 else {"k%d" % depth: level(depth + 1), "n%d" % depth: depth if rng.random() > 0.2 else None}
+    typ = pa.struct([("v", pa.int64()), ("s", pa.string()), ("l", pa.list_(pa.int32()))])
+    for depth in range(5, 0, -1):
+        typ = pa.struct([("k%d" % depth, typ), ("n%d" % depth, pa.int32())])
+    t = pa.table({"id": pa.array(np.arange(n)), "deep": pa.array([level(1) for _ in range(n)], type=typ)})
+    path = str(tmp_path / "deep.orc")
+    orc.write_table(t, path, compression="zstd", stripe_size=1 << 17)
+    want = orc.ORCFile(path).read()
+    for batch_size in (8192, 777):
+        got = table_of(read_all(path, batch_size=batch_size))
+        assert got.column("deep").combine_chunks().type == want.column("deep").combine_chunks().type
+        assert got.column("deep").combine_chunks().to_pylist() == want.column("deep").combine_chunks().to_pylist()
+
+
 # ---- Lists and Maps (list.rs:63-87, map.rs:74-104): offsets on the stripe's rows, the elements in a pass of their own -------
 @pytest.mark.parametrize("name", ["nested_array", "nested_map", "nested_array_float", "nested_array_struct", "nested_map_struct"])
 def test_the_references_nested_list_and_map_files(name):
@@ -176,14 +199,67 @@ def test_lists_and_maps_with_nulls_and_empties(tmp_path, compression, batch_size
             g, w = got.column(name).combine_chunks(), want.column(name).combine_chunks()
             assert g.type == w.type, (name, g.type, w.type)
             assert g.equals(w), name
-    # only a nested column; and a selection over it is refused (not built), over the flat columns beside it not
+    # only a nested column
     only = table_of(read_all(path, ["lol"], batch_size=batch_size))
     assert only.column("lol").combine_chunks().equals(want.column("lol").combine_chunks())
-    with pytest.raises(capi.OrcGpuError) as e:
-        read_all(path, ["id", "ints"], selection=[(10, True), (100, False)])
-    assert e.value.code == 7
     flat = table_of(read_all(path, ["id"], selection=[(10, True), (100, False), (n - 110, True)]))
     assert flat.column("id").to_pylist() == list(range(10, 110))
+
+
+def selected_rows(sel, n):
+    keep = np.zeros(n, dtype=bool)
+    at = 0
+    for cnt, skip in sel:
+        if not skip:
+            keep[at:at + cnt] = True
+        at += cnt
+    return keep
+
+
+def test_the_references_row_selections_over_nested_files():
+    """tests/row_selection/main.rs:237-304 (and their async twins :559-593): select / skip runs over nested_struct.orc and
+    nested_array.orc -- Lists are stepped like every other decoder (list.rs:89) --, and the same over nested_map.orc."""
+    for name, sel in (("nested_struct", [(2, False), (2, True), (1, False)]), ("nested_array", [(1, True), (2, False), (2, True)]),
+                      ("nested_map", [(1, True), (2, False), (2, True)]), ("nested_array_struct", [(1, False), (1, True), (1, False)]),
+                      ("nested_map_struct", [(1, True), (1, False)])):
+        path = A.data_path(name + ".orc")
+        want = A.expected_table(name)
+        n = want.num_rows
+        sel = [s for s in sel]
+        rest = n - sum(c for c, _ in sel)
+        if rest > 0:
+            sel.append((rest, True))
+        got = table_of(read_all(path, selection=sel))
+        exp = want.filter(pa.array(selected_rows(sel, n)[:n]))
+        assert got.num_rows == exp.num_rows, (name, got.num_rows, exp.num_rows)
+        for col in want.schema.names:
+            assert got.column(col).combine_chunks().to_pylist() == exp.column(col).combine_chunks().to_pylist(), (name, col)
+    # the reference's own expectation, literally (main.rs:293-302)
+    got = table_of(read_all(A.data_path("nested_array.orc"), selection=[(1, True), (2, False), (2, True)]))
+    assert got.column("value").to_pylist() == [[5, None, 32, 4, 15], [16, None, 3, 4, 5, 6]]
+
+
+@pytest.mark.parametrize("compression", ["zstd", "uncompressed"])
+@pytest.mark.parametrize("prefetch", [0, 2])
+def test_row_selection_over_lists_and_maps(tmp_path, compression, prefetch):
+    """Select runs that start and end inside stripes and batches, over List / Map columns with null Lists, empty Lists, null
+    elements, Lists of Lists, Lists of Structs, a List inside a Struct: the selected rows of the table PyArrow reads."""
+    n = 30_000
+    t = list_table(n, 9)
+    path = str(tmp_path / "lists_sel.orc")
+    orc.write_table(t, path, compression=compression, stripe_size=1 << 17)
+    f = orc.ORCFile(path)
+    assert f.nstripes >= 2
+    want = f.read()
+    sel = [(100, True), (5000, False), (9000, True), (3, False), (1, True), (1, False), (11995, True), (3000, False), (900, True)]
+    assert sum(c for c, _ in sel) == n
+    got = table_of(read_all(path, batch_size=8192, prefetch=prefetch, selection=sel))
+    exp = want.filter(pa.array(selected_rows(sel, n)))
+    assert got.num_rows == exp.num_rows
+    for name in want.schema.names:
+        g, w = got.column(name).combine_chunks(), exp.column(name).combine_chunks()
+        assert g.type == w.type, (name, g.type, w.type)
+        assert g.to_pylist() == w.to_pylist(), name
 
 
 # ---- Unions (array_decoder/union.rs:69-136): byte-RLE tags, one sparse child per arm ---------------------------------------
