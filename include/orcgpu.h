@@ -76,6 +76,9 @@ enum {
   ORCGPU_ARROW_TIMESTAMP_S_UTC = 21, ORCGPU_ARROW_TIMESTAMP_MS_UTC = 22, ORCGPU_ARROW_TIMESTAMP_US_UTC = 23, ORCGPU_ARROW_TIMESTAMP_NS_UTC = 24,
   ORCGPU_ARROW_TIMESTAMP_S_NOTZ = 31, ORCGPU_ARROW_TIMESTAMP_MS_NOTZ = 32, ORCGPU_ARROW_TIMESTAMP_US_NOTZ = 33, ORCGPU_ARROW_TIMESTAMP_NS_NOTZ = 34,
   ORCGPU_ARROW_TIMESTAMP_OTHER_TZ = 35,  /* Timestamp(_, Some(tz)) with tz != "UTC": UnsupportedTypeVariant for TimestampInstant */
+  /* nested targets (array_decoder/mod.rs:464-505): the hint of a Struct / List / Map / Union column; its children carry theirs */
+  ORCGPU_ARROW_STRUCT = 40, ORCGPU_ARROW_LIST = 41, ORCGPU_ARROW_MAP = 42, ORCGPU_ARROW_UNION = 43,
+  ORCGPU_ARROW_MAP_SORTED = 44,  /* Map with keys_sorted: UnsupportedTypeVariant "Sorted map" */
   ORCGPU_ARROW_OTHER = 99        /* any Arrow type the path has no decoder for */
 };
 

@@ -97,3 +97,61 @@ def test_stage_level_hint_is_checked():
     assert res.status()[0] == 0
     res.free()
     staged.free()
+
+
+# ---- nested columns take nested hints (array_decoder/mod.rs:464-505; struct_decoder.rs:43-48: children and fields zipped) ----
+def _rename(t, suffix):
+    """the same type with every field below it renamed"""
+    if pa.types.is_struct(t):
+        return pa.struct([pa.field(t.field(i).name + suffix, _rename(t.field(i).type, suffix)) for i in range(t.num_fields)])
+    if pa.types.is_list(t):
+        return pa.list_(pa.field("element" + suffix, _rename(t.value_type, suffix)))
+    if pa.types.is_map(t):
+        return pa.map_(_rename(t.key_type, suffix), _rename(t.item_type, suffix))
+    return t
+
+
+def _strip(v, suffix):
+    """to_pylist() of a renamed column with the suffix taken off the Struct keys again"""
+    if isinstance(v, dict):
+        return {k[:-len(suffix)] if k.endswith(suffix) else k: _strip(x, suffix) for k, x in v.items()}
+    if isinstance(v, list):
+        return [_strip(x, suffix) for x in v]
+    if isinstance(v, tuple):
+        return tuple(_strip(x, suffix) for x in v)
+    return v
+
+
+@pytest.mark.parametrize("name", ["nested_struct", "nested_array", "nested_map", "nested_array_struct", "nested_map_struct", "nested_array_float"])
+def test_schema_over_nested_columns(name):
+    expected = A.expected_table(name)
+    fields = [pa.field("r_" + f.name, _rename(f.type, "_x")) for f in expected.schema]
+    got = read_all(ArrowReaderBuilder.try_new(A.data_path(name + ".orc"), ctx=G.ctx()).with_schema(pa.schema(fields)))
+    assert got.column_names == [f.name for f in fields]
+    for i, f in enumerate(fields):
+        g = got.column(i).combine_chunks()
+        assert g.type == f.type, (name, g.type, f.type)   # the hinted names, all the way down
+        assert _strip(g.to_pylist(), "_x") == expected.column(i).combine_chunks().to_pylist(), (name, f.name)
+
+
+def test_mismatched_schema_inside_nested_columns():
+    exp = A.expected_table("nested_array")  # value: list<int64>
+    for wrong, code in ((pa.int64(), 6), (pa.list_(pa.string()), 6), (pa.struct([("a", pa.int64())]), 6), (pa.large_list(pa.int64()), 6)):
+        reader = ArrowReaderBuilder.try_new(A.data_path("nested_array.orc"), ctx=G.ctx()).with_schema(pa.schema([pa.field("value", wrong)])).build()
+        with pytest.raises(capi.OrcGpuError) as e:
+            next(iter(reader))
+        assert e.value.code == code, (wrong, e.value)
+    exp = A.expected_table("nested_struct")
+    st = exp.schema.field(0).type
+    wrong = pa.struct([pa.field(st.field(0).name, pa.string())] + [st.field(i) for i in range(1, st.num_fields)])  # one field of the Struct
+    reader = ArrowReaderBuilder.try_new(A.data_path("nested_struct.orc"), ctx=G.ctx()).with_schema(pa.schema([pa.field("nest", wrong)])).build()
+    with pytest.raises(capi.OrcGpuError) as e:
+        next(iter(reader))
+    assert e.value.code == 6, e.value
+    # a sorted Map: UnsupportedTypeVariant "Sorted map" (mod.rs:474)
+    mt = A.expected_table("nested_map").schema.field(0).type
+    reader = ArrowReaderBuilder.try_new(A.data_path("nested_map.orc"), ctx=G.ctx()).with_schema(
+        pa.schema([pa.field("map", pa.map_(mt.key_type, mt.item_type, keys_sorted=True))])).build()
+    with pytest.raises(capi.OrcGpuError) as e:
+        next(iter(reader))
+    assert e.value.code == 7, e.value
