@@ -290,6 +290,27 @@ int orcgpu_reader_set_projection_roots(orcgpu_reader* r, const uint32_t* root_in
  * for makes the first orcgpu_reader_next_batch return ORCGPU_MISMATCHED_SCHEMA.  The schema is read, not consumed. */
 int orcgpu_reader_set_schema(orcgpu_reader* r, const struct ArrowSchema* schema);
 int orcgpu_reader_set_byte_range(orcgpu_reader* r, uint64_t start, uint64_t end);                    /* with_file_byte_range */
+/* `world` processes, one per GPU, read ONE file together; this reader is number `rank` of them.  The units of the
+ * path are independent (stripe.rs:154-165: a stripe's columns are decoded one by one), so no data is exchanged -- each reader
+ * reads, stages and decodes only what is its own; what the ranks do with their batches (an all-gather of row counts,
+ * concatenation by column or by stripe) is the caller's.  The reference's own split hook is a byte range per reader
+ * (arrow_reader.rs:86-89, :358-372).
+ *   ORCGPU_SHARD_STRIPES  stripe k (of those the byte range leaves) belongs to rank k % world: whole stripes, every projected
+ *                         column.  A row selection is stepped through every stripe, read or not, so the ranks' batches put
+ *                         together in stripe order are the batches of a single reader.
+ *   ORCGPU_SHARD_COLUMNS  the projected root columns are dealt out by their estimated Arrow bytes per row (orcgpu_shard_columns:
+ *                         largest first, to the least loaded rank): every rank reads every stripe, its own columns only; its
+ *                         batches have the same rows as a single reader's, the ranks' columns put side by side are its columns.
+ * world = 1 (the default) reads everything. */
+enum { ORCGPU_SHARD_STRIPES = 0, ORCGPU_SHARD_COLUMNS = 1 };
+int orcgpu_reader_set_shard(orcgpu_reader* r, uint32_t rank, uint32_t world, int mode);
+/* The column deal alone (host only, no GPU): rank_of[i] for n columns of the given weights.  Longest-processing-time rule:
+ * columns in order of falling weight (ties: the earlier column first), each to the rank with the least weight so far (ties:
+ * the lower rank).  What orcgpu_reader_set_shard(.., ORCGPU_SHARD_COLUMNS) uses, with orcgpu_reader_column_weight's weights. */
+int orcgpu_shard_columns(const double* weights, uint32_t n, uint32_t world, uint32_t* rank_of);
+/* Estimated Arrow bytes per row of root column `root` of the file (its index among the root columns): fixed widths, 16 for
+ * Decimal128, 4 + 16 for strings and binaries, the sum of its fields for a Struct, offsets + two elements for Lists and Maps. */
+double orcgpu_reader_column_weight(const orcgpu_reader* r, uint32_t root);
 int orcgpu_reader_set_timestamp_precision(orcgpu_reader* r, int arrow_target);                       /* ORCGPU_ARROW_TIMESTAMP_* */
 /* with_row_selection (arrow_reader.rs:113): a selection over the rows of the FILE; every stripe takes its share with
  * RowSelection::split_off, and once no rows are left in the selection later stripes are read whole (arrow_reader.rs:296-308). */

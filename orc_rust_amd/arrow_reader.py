@@ -56,6 +56,12 @@ class ArrowReaderBuilder:
                 release(C.addressof(buf))
         return self
 
+    def with_shard(self, rank, world, mode="stripes"):
+        """This reader as number `rank` of `world` readers of the same file, one per GPU (orcgpu_reader_set_shard):
+        mode "stripes": stripe k belongs to rank k % world; "columns": the projected root columns dealt out by estimated Arrow bytes."""
+        self._ctx._check(self._ctx.L.orcgpu_reader_set_shard(self._h, rank, world, {"stripes": 0, "columns": 1}[mode]))
+        return self
+
     def with_file_byte_range(self, start, end):
         self._ctx._check(self._ctx.L.orcgpu_reader_set_byte_range(self._h, start, end))
         return self

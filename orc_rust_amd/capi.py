@@ -22,7 +22,7 @@ EXPORTS = [
     "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
     "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_fetch_async", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_timezone_offsets", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms",
     "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
-    "orcgpu_reader_set_projection", "orcgpu_reader_set_projection_roots", "orcgpu_reader_set_schema", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection", "orcgpu_reader_set_prefetch",
+    "orcgpu_reader_set_projection", "orcgpu_reader_set_projection_roots", "orcgpu_reader_set_schema", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_shard", "orcgpu_shard_columns", "orcgpu_reader_column_weight", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection", "orcgpu_reader_set_prefetch",
     "orcgpu_reader_set_row_group_pruning", "orcgpu_reader_row_groups", "orcgpu_index_entry", "orcgpu_reader_set_predicate",
     "orcgpu_predicate_row_groups",
     "orcgpu_reader_total_rows", "orcgpu_reader_stripe_count", "orcgpu_reader_column_count", "orcgpu_reader_column_name",
@@ -146,6 +146,10 @@ def load():
     L.orcgpu_result_fetch.argtypes = [C.c_void_p, C.c_void_p]
     L.orcgpu_result_fetch_async.argtypes = [C.c_void_p, C.c_void_p]
     L.orcgpu_reader_set_prefetch.argtypes = [C.c_void_p, C.c_uint32]
+    L.orcgpu_reader_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
+    L.orcgpu_shard_columns.argtypes = [C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.orcgpu_reader_column_weight.argtypes = [C.c_void_p, C.c_uint32]
+    L.orcgpu_reader_column_weight.restype = C.c_double
     from .predicate import ColumnIndex, PredicateNode
     L.orcgpu_reader_set_predicate.argtypes = [C.c_void_p, C.POINTER(PredicateNode), C.c_uint32]
     L.orcgpu_predicate_row_groups.argtypes = [C.POINTER(PredicateNode), C.c_uint32, C.POINTER(ColumnIndex), C.c_uint32, C.c_uint64, C.c_uint64,

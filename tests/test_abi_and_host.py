@@ -201,3 +201,63 @@ def test_two_rank_gloo_row_count_allgather(tmp_path):
              for r in range(2)]
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+# ---- the reader's shard spec (orcgpu_reader_set_shard; host logic: orcgpu_shard_columns) --------------------------------------
+def _deal(weights, world):
+    import ctypes as C
+    from orc_rust_amd import capi
+    L = capi.load()
+    w = (C.c_double * len(weights))(*weights)
+    out = (C.c_uint32 * max(1, len(weights)))()
+    assert L.orcgpu_shard_columns(w, len(weights), world, out) == 0
+    return [out[i] for i in range(len(weights))]
+
+
+def test_column_deal_is_the_longest_processing_time_rule():
+    lineitem = [8, 8, 8, 4, 16, 16, 16, 16, 20, 20, 4, 4, 4, 20, 20, 20]  # orcgpu_reader_column_weight of the 16 lineitem columns
+    for world in (1, 2, 3, 4, 8, 16, 32):
+        r = _deal(lineitem, world)
+        assert all(0 <= x < world for x in r)
+        load = [sum(w for w, x in zip(lineitem, r) if x == k) for k in range(world)]
+        # the rule's own guarantee: no rank above the mean by more than the heaviest column
+        assert max(load) <= sum(lineitem) / world + max(lineitem)
+        # a restatement in Python: falling weight (ties: earlier first), to the least loaded rank (ties: the lower)
+        ref_load, ref = [0.0] * world, [0] * len(lineitem)
+        for i in sorted(range(len(lineitem)), key=lambda i: (-lineitem[i], i)):
+            k = min(range(world), key=lambda k: (ref_load[k], k))
+            ref[i] = k
+            ref_load[k] += lineitem[i]
+        assert r == ref
+    assert _deal([], 4) == []
+
+
+_SHARD_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import torch.distributed as dist
+from test_abi_and_host import _deal
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+weights = [8, 8, 8, 4, 16, 16, 16, 16, 20, 20, 4, 4, 4, 20, 20, 20]
+mine = [i for i, r in enumerate(_deal(weights, world)) if r == rank]              # ORCGPU_SHARD_COLUMNS
+stripes = [k for k in range(35) if k %% world == rank]                            # ORCGPU_SHARD_STRIPES
+everyone = [None] * world
+dist.all_gather_object(everyone, (mine, stripes))
+cols = sorted(c for m, _ in everyone for c in m)
+assert cols == list(range(16)), cols                                             # every column exactly once
+assert sorted(s for _, st in everyone for s in st) == list(range(35))            # every stripe exactly once
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_rank_gloo_reader_shards_partition_the_file(tmp_path):
+    script = tmp_path / "shard_worker.py"
+    script.write_text(_SHARD_WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
