@@ -652,6 +652,10 @@ __device__ __forceinline__ uint32_t count_lds(const uint8_t* buf, const uint8_t*
 // pointer doubling inside the block makes next[p] the first position at or behind the block's end that the chain from p
 // reaches, and cnt[p] the values of the runs on the way.  Cost: 8 parses + at most 9 x 8 table updates per lane, whatever
 // the data -- no serial chain through the block, and no dependence on how quickly wrong chains merge with the true one.
+// (Tried in round 4, not kept: the doubling in registers -- eight sub-blocks of 64 positions, hops by ds_bpermute, composed
+// from the last sub-block backwards, only the finished table written to LDS: 168 cross-lane operations instead of ~430 LDS
+// accesses and no barrier per round, exact on the whole suite -- and 12 % SLOWER (C3's walk 0.61 -> 0.69 ms): the rounds are
+// not what a block costs.  Nor is the warm-up in front of a span: 32 -> 8 blocks made the repairs behind it cost more.)
 template <int CODEC>
 __device__ __forceinline__ void block_exit_table(const uint8_t* data, uint64_t len, uint32_t lbv, bool is_signed, int nbits, uint16_t (*tab)[RLE_BLK],
                                                  uint32_t lane, int& cur) {
