@@ -600,10 +600,25 @@ __device__ __forceinline__ void varint_terms_body(const uint8_t* s, const uint64
   tpop[w] = (uint32_t)__builtin_popcountll(m);
 }
 
-// pass 2: one thread per stream byte; terminators decode their varint into dense[k]
+// A value of scale `vs` at the column's scale (array_decoder/decimal.rs:138-166; release-build wrapping)
+__device__ __forceinline__ __int128 decimal_rescale(__int128 v, uint32_t vs, uint32_t fixed_scale) {
+  if (vs == fixed_scale) return v;
+  const uint32_t k = fixed_scale < vs ? vs - fixed_scale : fixed_scale - vs;
+  unsigned __int128 f = 1;
+  for (uint32_t t = 0; t < k && t < 200; t++) f *= 10;
+  if (fixed_scale < vs) {
+    const __int128 sf = (__int128)f;
+    return sf != 0 ? v / sf : v;
+  }
+  return (__int128)((unsigned __int128)v * f);
+}
+
+// pass 2: one thread per stream byte; terminators decode their varint into dense[k].  `scales` (a column without nulls: value k
+// IS row k): the value is brought to the column's scale here and `dense` is the column's Arrow buffer -- decimal_finish_body, a
+// pass over 36 bytes per value that only re-reads what this one has just written, is not run.
 __device__ __forceinline__ void varint_decode128_body(const uint8_t* s, const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx,
                                                                            const unsigned long long* tmask, const uint32_t* trank, __int128* dense,
-                                                                           uint64_t n_upper, unsigned long long* err) {
+                                                                           uint64_t n_upper, unsigned long long* err, const int32_t* scales, uint32_t fixed_scale) {
   uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t len = scalars[len_idx];
   if (len > n_upper) len = n_upper;
@@ -643,7 +658,7 @@ __device__ __forceinline__ void varint_decode128_body(const uint8_t* s, const ui
       u |= (v >> 6) & (0x7full << 42);
       // (bytes behind the terminator do not exist in v: the shift brought zeros in; the terminator's own flag is clear)
       const int64_t z = (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
-      dense[k] = (__int128)z;
+      dense[k] = scales ? decimal_rescale((__int128)z, (uint32_t)scales[k], fixed_scale) : (__int128)z;
       if (p == len - 1 && k + 1 < needed) report_err64(err, k + 1, ORC_E_IO);
       return;
     }
@@ -658,7 +673,7 @@ __device__ __forceinline__ void varint_decode128_body(const uint8_t* s, const ui
   unsigned __int128 u = 0;
   for (uint32_t i = 0; i < nb; i++) u |= (unsigned __int128)(s[start + i] & 0x7f) << (7 * i);
   unsigned __int128 z = (u >> 1) ^ (unsigned __int128)(-(__int128)(u & 1));
-  dense[k] = (__int128)z;
+  dense[k] = scales ? decimal_rescale((__int128)z, (uint32_t)scales[k], fixed_scale) : (__int128)z;
   // "not enough values": the last terminator knows how many values exist
   if (p == len - 1 && k + 1 < needed) report_err64(err, k + 1, ORC_E_IO);
 }
@@ -681,20 +696,6 @@ __device__ __forceinline__ void decimal_finish_body(const __int128* dense, const
     d = (uint64_t)rank[i >> 6] + __builtin_popcountll(word & ((1ull << bit) - 1));
   }
   __int128 v = 0;
-  if (valid) {
-    v = dense[d];
-    uint32_t vs = (uint32_t)scales[d];
-    if (vs != fixed_scale) {
-      uint32_t k = fixed_scale < vs ? vs - fixed_scale : fixed_scale - vs;
-      unsigned __int128 f = 1;
-      for (uint32_t t = 0; t < k && t < 200; t++) f *= 10;
-      if (fixed_scale < vs) {
-        __int128 sf = (__int128)f;
-        if (sf != 0) v = v / sf;
-      } else {
-        v = (__int128)((unsigned __int128)v * f);
-      }
-    }
-  }
+  if (valid) v = decimal_rescale(dense[d], (uint32_t)scales[d], fixed_scale);
   out[i] = v;
 }
