@@ -57,7 +57,7 @@ PHASE_KERNELS = {
     "decompress": "block decompression of every chunk of the call",
     "decompress_stage1": {"zstd": "zstd_entropy_kernel (FSE sequences + Huffman literals, one wavefront per block)",
                           "snappy": "lz_parse_kernel (token stage, one workgroup per chunk)", "lz4": "lz_parse_kernel (token stage, one workgroup per chunk)"},
-    "decompress_sequences": "zstd_seq_lanes16_kernel (FSE sequences, one lane per block; the Huffman literals kernel runs beside it)",
+    "decompress_sequences": "zstd_seq_quads_kernel (FSE sequences, four lanes per block; the Huffman literals kernel runs beside it)",
     "decompress_stage2_wave": "lz_exec_wave_kernel (LZ77 execution, one wavefront per chunk)",
     "decompress_stage2": {"zstd": "lz_exec_kernel (LZ77 execution, one workgroup per chunk)", "snappy": "lz_exec_tokens_kernel (LZ77 execution, one workgroup per chunk)",
                           "lz4": "lz_exec_tokens_kernel (LZ77 execution, one workgroup per chunk)", "zlib": "decompress_deflate_kernel (one wavefront per chunk)"},
