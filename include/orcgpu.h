@@ -381,6 +381,17 @@ const char* orcgpu_reader_column_name(orcgpu_reader* r, uint32_t i);
  * anything else = the OrcError status of the failing batch (the iterator then ends). */
 int orcgpu_reader_next_batch(orcgpu_reader* r, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 
+/* ---- GPU encode: Integer RLE v2 of an Int64 column ---------------------------------------- */
+/* Replaces RleV2Encoder<i64, S>::{write_slice, take_inner} (src/encoding/integer/rle_v2/mod.rs:403-531; the seam is
+ * PrimitiveValueEncoder, src/encoding/mod.rs:36-50; a column's encoder is flushed per stripe by src/writer/stripe.rs:109-165):
+ * `n` values (host memory) -> the bytes of an RLE v2 stream in `out` (host memory), *out_len of them.  is_signed: zigzag, as the
+ * reference's SignedEncoding.  Runs are cut every 512 values -- one wavefront per run -- and take the sub-encoding that fits:
+ * SHORT_REPEAT (3..10 equal values), DELTA with a fixed step (an arithmetic progression), else DIRECT at the run's width;
+ * PATCHED_BASE is never chosen.  The stream is one valid encoding of the values, not byte for byte the reference encoder's
+ * (a greedy state machine over single values); every decoder -- rle_expand.hip, the oracle, the reference -- reads the values back.
+ * out = NULL (or out_cap too small: ORCGPU_INVALID_ARGUMENT) only reports the size in *out_len. */
+int orcgpu_encode_rle2_i64(orcgpu_ctx* ctx, const int64_t* values, uint64_t n, int is_signed, uint8_t* out, uint64_t out_cap, uint64_t* out_len);
+
 /* ---- timing hooks used by bench.py (HIP events on the context's own stream) ---------------------- */
 /* Milliseconds the device spent in the last orcgpu_decode_staged call, whole call and the RLE
  * expansion kernels alone (the dominant kernel), measured with hipEvents on the ctx stream. */

@@ -42,6 +42,7 @@
 #include "device/string_kernels.hip"
 #include "device/decompress_kernels.hip"
 #include "device/select_kernels.hip"
+#include "device/rle_encode.hip"
 
 // Arrow C Data Interface structs (public, stable ABI)
 extern "C" {
@@ -1111,3 +1112,4 @@ struct SummaryLayout {
 #include "orcgpu_export.inc"
 #include "orcgpu_select.inc"
 #include "orcgpu_reader.inc"
+#include "orcgpu_encode.inc"
