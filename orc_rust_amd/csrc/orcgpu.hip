@@ -273,6 +273,29 @@ struct orcgpu_ctx {
     int64_t epoch = 1420070400;
   };
   std::map<std::string, std::shared_ptr<Zone>> zones;
+  // Job tables on their way to HBM go through pinned staging: hipMemcpyAsync from pageable memory makes the host wait for the
+  // stream, which then runs dry while the host enqueues what follows.  Bump-allocated; taken back when a call starts (behind a
+  // stream synchronisation: nothing is in flight from it any more).
+  std::vector<std::pair<uint8_t*, size_t>> up_blocks;
+  size_t up_block = 0, up_off = 0;
+  void upload_reset() { up_block = up_off = 0; }
+  hipError_t upload(void* dst, const void* src, size_t n, hipStream_t st) {
+    if (!n) return hipSuccess;
+    const size_t need = (n + 63) & ~(size_t)63;
+    while (up_block < up_blocks.size() && up_off + need > up_blocks[up_block].second) up_block++, up_off = 0;
+    if (up_block == up_blocks.size()) {
+      uint8_t* b = nullptr;
+      const size_t cap = std::max<size_t>(2 * need, 1u << 20);
+      hipError_t e = hipHostMalloc((void**)&b, cap, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      up_blocks.push_back({b, cap});
+      up_off = 0;
+    }
+    uint8_t* h = up_blocks[up_block].first + up_off;
+    up_off += need;
+    memcpy(h, src, n);
+    return hipMemcpyAsync(dst, h, n, hipMemcpyHostToDevice, st);
+  }
   bool ensure_pinned(size_t n) {
     if (n <= pinned_cap) return true;
     if (pinned) (void)hipHostFree(pinned);
@@ -728,6 +751,7 @@ void orcgpu_close(orcgpu_ctx* c) {
   if (c->d2h_gate) (void)hipEventDestroy(c->d2h_gate);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->fin_pinned) (void)hipHostFree(c->fin_pinned);
+  for (auto& b : c->up_blocks) (void)hipHostFree(b.first);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : c->aux_ev)
