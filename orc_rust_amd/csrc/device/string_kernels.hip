@@ -409,6 +409,30 @@ __device__ __forceinline__ void dict_emit_body(const DictJob& j, uint64_t dict_n
   if (tid == 0) out[rows] = (int32_t)carry;
 }
 
+// Between the passes: the value bytes of a result's dictionary columns are placed one behind the other in its character arena,
+// here on the device -- the host, which used to wait for the totals of pass 1 to do it, places them the same way when the call
+// is over, and sends pass 2 again in the rare case the arena (sized by the result's earlier use) proved too small: then the
+// columns from the first misfit on get no value bytes from this launch (out_chars null), only their offsets.
+struct DictPlace {
+  uint8_t* base;   // the result's character arena
+  uint64_t cap;
+  uint32_t first, count;  // its jobs in the table
+};
+extern "C" __global__ void __launch_bounds__(64) dict_place_kernel(DictJob* jobs, const DictPlace* places, uint32_t n_places, uint64_t pad, uint64_t align) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_places) return;
+  const DictPlace pl = places[i];
+  uint64_t need = 0;
+  bool over = false;
+  for (uint32_t k = pl.first; k < pl.first + pl.count; k++) {
+    const uint64_t total = *glob(jobs[k].total_out);
+    const uint64_t off = (need + align - 1) & ~(align - 1);
+    need = off + total + pad;
+    over = over || need + align > pl.cap;
+    jobs[k].out_chars = (!over && total) ? pl.base + off : nullptr;
+  }
+}
+
 extern "C" __global__ void __launch_bounds__(256) dict_emit_kernel(const DictJob* jobs, const uint64_t* scalars) {
   __shared__ __attribute__((aligned(16))) uint8_t chars[DICT_CHARS_LDS + 16];
   __shared__ uint16_t doffc[DICT_DOFF_LDS + 2];

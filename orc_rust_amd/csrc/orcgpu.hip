@@ -682,6 +682,9 @@ struct Plan {
   uint64_t spacejobs_off = 0;          // device copy of the SpaceJob table
   std::vector<SpaceJob> spacejobs;
   std::vector<DictJob> dictjobs;       // host copy, same order as pending_gathers
+  uint64_t dictplaces_off = 0;         // device copy of the DictPlace table
+  std::vector<DictPlace> dictplaces;   // per result with dictionary columns: its arena as pass 2 was launched (empty: the host placed them itself)
+  std::vector<uint32_t> dictplace_result;
   uint32_t decomp_chunks = 0;        // chunks of the streams in `decomp` so far
   std::vector<DecompStream> decomp;  // compressed streams to expand before anything else  // indices into cols: dictionary string columns waiting for their gather
   uint32_t new_scalar(uint64_t v) {

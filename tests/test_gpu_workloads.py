@@ -129,3 +129,37 @@ def test_zstd_chunks_put_off_by_the_streaming_pass_are_taken_again(monkeypatch):
     assert res.status()[0] == 0, res.status()
     W.check_result(res, cols, expect)
     res.free()
+
+
+def test_dictionary_columns_into_results_used_before():
+    """A result decoded into again keeps its character arena: the value bytes of its dictionary columns are then placed on the
+    device without the host waiting for their totals (dict_place_kernel), and pass 2 is sent again when the arena proves too
+    small.  The same results take: small stripes (fresh: the host places), larger ones (too small: again), smaller ones (fit),
+    lineitem stripes (four dictionary columns each, arenas from a one-column stripe: again), the same once more (fit)."""
+    c = G.ctx()
+    table = W.lineitem_table(260_000)
+
+    def li(a, b):
+        return W.lineitem_stripe(table, a, b, "snappy")
+
+    rounds = [
+        [W.c3_stripe(40_000, 0, "snappy"), W.c3_stripe(9_000, 1, "snappy")],
+        [W.c3_stripe(700_000, 2, "snappy"), W.c3_stripe(350_000, 3, "snappy")],
+        [W.c3_stripe(100_001, 4, "snappy"), W.c3_stripe(8_192, 5, "snappy")],
+        [li(0, 150_000), li(150_000, 260_000)],
+        [li(150_000, 260_000), li(0, 150_000)],
+    ]
+    results = None
+    for no, stripes in enumerate(rounds):
+        staged = [c.stage(n, streams, cols, compression="snappy") for n, cols, streams, _ in stripes]
+        results = c.decode(staged, results)
+        for s in staged:
+            s.free()
+        for (n, cols, streams, expect), res in zip(stripes, results):
+            assert res.status()[0] == 0, (no, res.status())
+            W.check_result(res, cols, expect)
+            for ci, cc in enumerate(cols):
+                if cc.get("encoding") in (W.DICTIONARY_V2,):
+                    G.assert_column_parity(res, ci, cc, streams, n, 8192, compression="snappy", what=("reused result", no, cc.get("name")))
+    for res in results:
+        res.free()
