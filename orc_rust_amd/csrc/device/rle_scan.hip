@@ -127,8 +127,9 @@ __device__ __forceinline__ void walk_dispatch(const RleJob* j, const uint8_t* da
 // block's first header is.  A stream's entries start with its first byte.  Entries that are not in order, or a chain that
 // does not arrive exactly at the next entry, mark the job: the guess round then ignores its hints.
 template <int CODEC>
-__device__ __forceinline__ bool hint_chain(const uint8_t* data, uint64_t len, uint64_t p, uint64_t end, bool is_signed, int nbits, uint32_t* hint) {
+__device__ __forceinline__ bool hint_chain(const uint8_t* data, uint64_t len, uint64_t p, uint64_t end, bool is_signed, int nbits, uint32_t* hint, uint32_t max_hops) {
   while (p < end) {
+    if (!max_hops--) return true;  // (the last entry of a stream: what lies far behind it is left to the ordinary walk)
     uint32_t hsize, hn, herr;
     hop_parse<CODEC>(data + p, len - p, is_signed, nbits, hsize, hn, herr);
     if (herr || !hsize) return false;  // (a run that does not parse: the ordinary walk deals with the stream)
@@ -165,10 +166,13 @@ extern "C" __global__ void __launch_bounds__(64) rle_hint_kernel(RleJob* jobs, c
     hint[0] = 0;
   }
   const uint8_t* data = as_global(j->data);
+  // A stream's last entry has no next one to arrive at: its lane follows a thousand runs (a stream may reach far beyond the
+  // rows asked for: 40 000 short runs were 20 ms for one lane)
+  const uint32_t max_hops = t + 1 < j->hint0 + j->n_hints ? 0xffffffffu : 1024u;
   bool ok;
-  if (j->codec == CODEC_RLE2) ok = hint_chain<CODEC_RLE2>(data, len, (uint64_t)p0, (uint64_t)p1, j->is_signed, j->nbits, hint);
-  else if (j->codec == CODEC_RLE1) ok = hint_chain<CODEC_RLE1>(data, len, (uint64_t)p0, (uint64_t)p1, j->is_signed, j->nbits, hint);
-  else ok = hint_chain<CODEC_BYTE>(data, len, (uint64_t)p0, (uint64_t)p1, false, 8, hint);
+  if (j->codec == CODEC_RLE2) ok = hint_chain<CODEC_RLE2>(data, len, (uint64_t)p0, (uint64_t)p1, j->is_signed, j->nbits, hint, max_hops);
+  else if (j->codec == CODEC_RLE1) ok = hint_chain<CODEC_RLE1>(data, len, (uint64_t)p0, (uint64_t)p1, j->is_signed, j->nbits, hint, max_hops);
+  else ok = hint_chain<CODEC_BYTE>(data, len, (uint64_t)p0, (uint64_t)p1, false, 8, hint, max_hops);
   if (!ok) atomicOr(&j->hint_bad, 1u);
 }
 
