@@ -34,7 +34,7 @@ for c in none snappy zstd lz4 zlib; do run c3_$c --workload c3 --compression $c;
 for c in none snappy; do run c3_${c}_index --workload c3 --compression $c --row-index; done
 run c5_lz4 --workload c5 --compression lz4
 # 3b. the timeline of one headline step (kernel, queue, start, end): what runs beside what
-( cd $R && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/raw_trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu --skip-check --no-e2e > /dev/null 2> $O/prof_trace.err )
+( cd $R && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/raw_trace -- python3 bench.py --steps 4 --warmup 3 --no-cpu --skip-check --no-e2e > /dev/null 2> $O/prof_trace.err )
 f=$(find $O/raw_trace -name '*kernel_trace.csv' | head -1)
 [ -n "$f" ] && python3 - "$f" > $O/timeline_lineitem_zstd.txt <<'PY'
 import csv, sys
