@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     from orc_rust_amd import capi
     L = capi.load()
     hdr = open(os.path.join(ROOT, "include", "orcgpu.h")).read()
-    declared = sorted(set(re.findall(r"\b(orcgpu_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(orcgpu_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 15
     missing = [n for n in declared if not hasattr(L, n)]
     assert not missing, missing
