@@ -661,7 +661,7 @@ __device__ __forceinline__ uint32_t count_lds(const uint8_t* buf, const uint8_t*
 // accesses and no barrier per round, exact on the whole suite -- and 12 % SLOWER (C3's walk 0.61 -> 0.69 ms): the rounds are
 // not what a block costs.  Nor is the warm-up in front of a span: 32 -> 8 blocks made the repairs behind it cost more.)
 template <int CODEC>
-__device__ __forceinline__ void block_exit_table(const uint8_t* data, uint64_t len, uint32_t lbv, bool is_signed, int nbits, uint16_t (*tab)[RLE_BLK],
+__device__ __forceinline__ void block_exit_table(const uint8_t* data, uint64_t len, uint32_t lbv, bool is_signed, int nbits, uint32_t (*tab)[RLE_BLK],
                                                  uint32_t lane, int& cur) {
   const uint64_t bstart = (uint64_t)lbv * RLE_BLK;
   const uint32_t limit = len - bstart < RLE_BLK ? (uint32_t)(len - bstart) : RLE_BLK;  // positions below it lie inside the stream
@@ -686,27 +686,24 @@ __device__ __forceinline__ void block_exit_table(const uint8_t* data, uint64_t l
       nx = to < 0xffffu ? to : 0xfffeu;
       c = err ? 0u : n;
     }
-    tab[0][p] = (uint16_t)nx;
-    tab[1][p] = (uint16_t)c;
+    tab[0][p] = (nx & 0xffffu) | (c << 16);  // one word per position: where the chain from it is (low half), the values on the way (16 bits, wrapping)
   }
   wave_sync_scan();
   for (int round = 0; round < 10; round++) {
-    uint16_t* nx0 = tab[2 * cur];
-    uint16_t* cn0 = tab[2 * cur + 1];
-    uint16_t* nx1 = tab[2 * (cur ^ 1)];
-    uint16_t* cn1 = tab[2 * (cur ^ 1) + 1];
+    const uint32_t* t0 = tab[cur];
+    uint32_t* t1 = tab[cur ^ 1];
     bool changed = false;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       const uint32_t p = lane + 64u * i;
-      uint32_t q = nx0[p], c = cn0[p];
+      uint32_t v = t0[p];
+      const uint32_t q = v & 0xffffu;
       if (q < limit) {
-        c += cn0[q];
-        q = nx0[q];
+        const uint32_t w = t0[q];
+        v = (w & 0xffffu) | ((v & 0xffff0000u) + (w & 0xffff0000u));
         changed = true;
       }
-      nx1[p] = (uint16_t)q;
-      cn1[p] = (uint16_t)c;
+      t1[p] = v;
     }
     wave_sync_scan();
     cur ^= 1;
@@ -721,7 +718,7 @@ __device__ __forceinline__ void block_exit_table(const uint8_t* data, uint64_t l
 // One span by a workgroup of RLE_SHORT_WAVES wavefronts: per round every wave builds the all-entries table of one block
 // (block_exit_table: the expensive, entry-independent part), then the chain takes one table lookup per block.
 template <int CODEC>
-__device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t lb0, uint32_t b0g, uint16_t (*tabs)[4][RLE_BLK],
+__device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t lb0, uint32_t b0g, uint32_t (*tabs)[2][RLE_BLK],
                                            int* curs, uint32_t tid, unsigned long long live_m, unsigned long long weak_m PROF_PARM) {
   const uint8_t* data = as_global(j->data);
   const bool is_signed = j->is_signed;
@@ -771,8 +768,9 @@ __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint
           ex = 0;
         } else {
           const int cur = curs[w];
-          const uint32_t to = tabs[w][2 * cur][e];
-          nv = tabs[w][2 * cur + 1][e];
+          const uint32_t v = tabs[w][cur][e];
+          const uint32_t to = v & 0xffffu;
+          nv = v >> 16;
           ex = to > RLE_BLK ? to - RLE_BLK : 0u;
         }
       }
@@ -791,7 +789,7 @@ __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint
 
 extern "C" __global__ void __launch_bounds__(64 * RLE_SHORT_WAVES) rle_walk_short_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
                                                                                           uint32_t total_blocks, uint32_t spans_per_wg) {
-  __shared__ uint16_t tabs[RLE_SHORT_WAVES][4][RLE_BLK];
+  __shared__ uint32_t tabs[RLE_SHORT_WAVES][2][RLE_BLK];
   __shared__ int curs[RLE_SHORT_WAVES];
   __shared__ unsigned long long masks[8][2];
   const uint32_t tid = threadIdx.x, lane = tid & 63;
