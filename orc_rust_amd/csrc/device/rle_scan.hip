@@ -711,7 +711,11 @@ __device__ __forceinline__ void block_exit_table(const uint8_t* data, uint64_t l
   }
 }
 
-#define RLE_SHORT_WAVES 8
+#ifndef RLE_SHORT_WAVES
+#define RLE_SHORT_WAVES 8  // (4: the same for C3, 5 % slower on the lineitem stripes; 16: 50 % slower.  Per-wavefront clocks of the kernel on C3
+                           // (-DORC_PROF): parsing the positions 35 %, the doubling rounds 12 %, the chain's lookups 12 %, waiting at the two barriers of a
+                           // round 39 % -- with the chain's three stores per block moved out from between them: the same)
+#endif
 #ifndef RLE_SHORT_MIN_WEAK
 #define RLE_SHORT_MIN_WEAK 16  // unverified blocks (of 64) that make a span a short-run span; fewer: the relaxation rounds and rle_mend_kernel
 #endif
