@@ -719,82 +719,75 @@ __device__ __forceinline__ void block_exit_table(const uint8_t* data, uint64_t l
 #ifndef RLE_SHORT_MIN_WEAK
 #define RLE_SHORT_MIN_WEAK 16  // unverified blocks (of 64) that make a span a short-run span; fewer: the relaxation rounds and rle_mend_kernel
 #endif
-// One span by a workgroup of RLE_SHORT_WAVES wavefronts: per round every wave builds the all-entries table of one block
-// (block_exit_table: the expensive, entry-independent part), then the chain takes one table lookup per block.
+// One span by a workgroup of RLE_SHORT_WAVES wavefronts: wavefront w takes the blocks k0 + w, + RLE_SHORT_WAVES, ...: it builds the
+// block's all-entries table (block_exit_table: the expensive, entry-independent part), waits for the exit of the block before
+// -- published in LDS by the wavefront that has it --, looks its own exit up and publishes it.  No barrier inside a span: with
+// one around every round of tables the wavefronts spent 39 % of the kernel waiting for the slowest of them (-DORC_PROF); here a
+// slow wavefront delays the lookups behind it, not the tables the others build meanwhile.
 template <int CODEC>
 __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t lb0, uint32_t b0g, uint32_t (*tabs)[2][RLE_BLK],
-                                           int* curs, uint32_t tid, unsigned long long live_m, unsigned long long weak_m PROF_PARM) {
+                                           volatile uint32_t* exits, volatile uint32_t* ready, uint32_t tid, unsigned long long live_m,
+                                           unsigned long long weak_m PROF_PARM) {
   const uint8_t* data = as_global(j->data);
   const bool is_signed = j->is_signed;
   const int nbits = j->nbits;
   const uint32_t lane = tid & 63, wv = tid >> 6;
   const uint32_t wstart = lb0 >= RLE_WARM ? lb0 - RLE_WARM : 0u;
   const uint32_t nwarm = lb0 - wstart;
+  for (uint32_t i = tid; i < RLE_WARM + 64; i += 64 * RLE_SHORT_WAVES) ready[i] = 0;
+  __syncthreads();
   // The warm-up blocks in front of the span come first (entry 0 at the first one: a chain started at a wrong byte merges
   // with the true chain after a few run lengths), then the span's own.  A weak block enters where its predecessor's last
   // run ended, a strong one at its verified header.
   const bool first_weak = weak_m & 1;
-  uint32_t run_exit = 0;  // where the previous block's last run ended (relative to this block's start)
   const uint32_t k0 = (nwarm > 0 && first_weak) ? 0u : nwarm;
-  for (uint32_t kr = k0; kr < nwarm + 64; kr += RLE_SHORT_WAVES) {
-    {
-      const uint32_t k = kr + wv;
-      const bool in_span = k >= nwarm;
-      const bool there = k < nwarm + 64 && (!in_span || ((live_m >> (k - nwarm)) & 1)) && (uint64_t)(wstart + k) * RLE_BLK < len;
-      int cur = 0;
-      if (there) block_exit_table<CODEC>(data, len, wstart + k, is_signed, nbits, tabs[wv], lane, cur);
-      if (lane == 0) curs[wv] = cur;
-    }
-    __syncthreads();
-    bool done = false;
-    for (uint32_t w = 0; w < RLE_SHORT_WAVES; w++) {
-      const uint32_t k = kr + w;
-      if (k >= nwarm + 64) break;
-      const bool in_span = k >= nwarm;
-      const uint32_t sl = k - nwarm;
-      if (in_span && !((live_m >> sl) & 1)) {
-        done = true;
-        break;
-      }
-      const bool bweak = !in_span || ((weak_m >> sl) & 1);
+  for (uint32_t k = k0 + wv; k < nwarm + 64; k += RLE_SHORT_WAVES) {
+    const bool in_span = k >= nwarm;
+    const uint32_t sl = k - nwarm;
+    const bool live = !in_span || ((live_m >> sl) & 1);  // (behind the stream's last block: nothing but the word to those who wait)
+    const bool bweak = !in_span || ((weak_m >> sl) & 1);
+    uint32_t e = 0, ex = 0, nv = 0;
+    if (live) {
       const uint32_t lbv = wstart + k;
-      uint32_t e;
-      if (!bweak) e = blk.entry[b0g + sl];
-      else if (k == k0) e = 0;  // (first warm-up block, or the stream's first block)
-      else e = run_exit;
-      uint32_t ex, nv = 0;
+      const uint64_t bstart = (uint64_t)lbv * RLE_BLK;
+      const uint32_t limit = bstart >= len ? 0u : (len - bstart < RLE_BLK ? (uint32_t)(len - bstart) : RLE_BLK);
+      const uint32_t e_given = bweak ? 0u : blk.entry[b0g + sl];  // (on its way while the table is built)
+      int cur = 0;
+      if (limit) block_exit_table<CODEC>(data, len, lbv, is_signed, nbits, tabs[wv], lane, cur);
+      if (!bweak) {
+        e = e_given;
+      } else if (k != k0) {  // (k0: the first warm-up block, or the stream's first block: entry 0)
+        uint32_t spins = 0;
+        while (!ready[k - 1] && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);  // (the bound: whatever happens, the kernel ends -- and the verify rounds see the rest)
+        e = exits[k - 1];  // where the previous block's last run ended (relative to this block's start)
+      }
       if (e >= RLE_BLK) {
         ex = e - RLE_BLK;
-      } else {
-        const uint64_t bstart = (uint64_t)lbv * RLE_BLK;
-        const uint32_t limit = bstart >= len ? 0u : (len - bstart < RLE_BLK ? (uint32_t)(len - bstart) : RLE_BLK);
-        if (e >= limit) {
-          ex = 0;
-        } else {
-          const int cur = curs[w];
-          const uint32_t v = tabs[w][cur][e];
-          const uint32_t to = v & 0xffffu;
-          nv = v >> 16;
-          ex = to > RLE_BLK ? to - RLE_BLK : 0u;
-        }
+      } else if (e < limit) {
+        const uint32_t v = tabs[wv][cur][e];
+        const uint32_t to = v & 0xffffu;
+        nv = v >> 16;
+        ex = to > RLE_BLK ? to - RLE_BLK : 0u;
       }
-      run_exit = ex;
-      if (in_span && bweak && tid == 0) {
+    }
+    if (lane == 0) {
+      exits[k] = ex;
+      ready[k] = 1;
+      if (live && in_span && bweak) {
         blk.entry[b0g + sl] = e;
         blk.exit_[b0g + sl] = ex;
         blk.nvals[b0g + sl] = nv;
       }
     }
-    __syncthreads();
-    if (done) break;
   }
+  __syncthreads();  // (the next span takes the flags back)
   PROF_MARK(7);
 }
 
 extern "C" __global__ void __launch_bounds__(64 * RLE_SHORT_WAVES) rle_walk_short_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
                                                                                           uint32_t total_blocks, uint32_t spans_per_wg) {
   __shared__ uint32_t tabs[RLE_SHORT_WAVES][2][RLE_BLK];
-  __shared__ int curs[RLE_SHORT_WAVES];
+  __shared__ uint32_t exits[RLE_WARM + 64], ready[RLE_WARM + 64];
   __shared__ unsigned long long masks[8][2];
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   // up to eight spans per workgroup (the host picks a power of two; block ranges of a job are
@@ -826,9 +819,9 @@ extern "C" __global__ void __launch_bounds__(64 * RLE_SHORT_WAVES) rle_walk_shor
     // isolated weak blocks inside long-run streams are left to the relaxation rounds
     if (__builtin_popcountll(weak_m) < RLE_SHORT_MIN_WEAK) continue;
     uint32_t bw = bw8 + s * 64, lb0 = bw - j->block0;
-    if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, tabs, curs, tid, live_m, weak_m PROF_ARG);
-    else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, tabs, curs, tid, live_m, weak_m PROF_ARG);
-    else short_span<CODEC_BYTE>(j, blk, len, lb0, bw, tabs, curs, tid, live_m, weak_m PROF_ARG);
+    if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, tabs, exits, ready, tid, live_m, weak_m PROF_ARG);
+    else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, tabs, exits, ready, tid, live_m, weak_m PROF_ARG);
+    else short_span<CODEC_BYTE>(j, blk, len, lb0, bw, tabs, exits, ready, tid, live_m, weak_m PROF_ARG);
 #ifdef ORC_PROF
     if (tid == 0) atomicAdd(&g_prof[42], 1ull);
 #endif
