@@ -322,6 +322,7 @@ struct orcgpu_staged {
   // the file reader's row selection on these rows, as the batches it yields (rows counted from the first row staged)
   bool has_sel = false;
   std::vector<SelBatch> sel;
+  bool piece = false;  // some row groups of a stripe (what a selection leaves of it), not the stripe
   const StagedStream* find(uint32_t col, int kind) const {
     for (auto& s : streams)
       if (s.column_id == col && s.kind == kind) return &s;
