@@ -972,6 +972,10 @@ __device__ __forceinline__ void repair_chain(RleJob* j, const RleBlocks& blk, ui
 // up in the verify round that follows (mode 5) and is taken again; what is left after the passes goes to the serial
 // rle_repair_kernel, which is exact whatever happened before.  Streams with only a few inconsistent blocks skip all this
 // (RLE_MEND_MIN): the serial kernel is quicker for them.
+// (More passes do mend what two leave -- the adversarial stream of bench.py's c2-adv, whose spans' warm-ups rarely meet the true
+// chain: 2 passes + the serial repair 23 ms, 12 passes 7.6, 24 passes 6.1 -- but every pass is two launches on every call; and the
+// passes looped inside ONE workgroup per stream, a launch that ends at once for all other streams, took 37 ms: a single workgroup
+// going over 55 000 blocks is bound by its own memory latency.  Such streams are what the ROW_INDEX positions are for: 0.56 ms.)
 #define RLE_MEND_STEPS 64
 #define RLE_MEND_NEAR 48u
 extern "C" __global__ void __launch_bounds__(256) rle_mend_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars, uint32_t total_blocks) {
