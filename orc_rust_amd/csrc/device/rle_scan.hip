@@ -785,7 +785,10 @@ __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint
   PROF_MARK(7);
 }
 
-extern "C" __global__ void __launch_bounds__(64 * RLE_SHORT_WAVES) rle_walk_short_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
+#ifndef RLE_SHORT_MIN_WAVES
+#define RLE_SHORT_MIN_WAVES 8  // (the kernel came to 66 registers: 7 wavefronts per SIMD, three workgroups per CU where its LDS allows four.  Held to 64 -- no spills --: C3's walk 0.46 -> 0.40 ms)
+#endif
+extern "C" __global__ void __launch_bounds__(64 * RLE_SHORT_WAVES, RLE_SHORT_MIN_WAVES) rle_walk_short_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
                                                                                           uint32_t total_blocks, uint32_t spans_per_wg) {
   __shared__ uint32_t tabs[RLE_SHORT_WAVES][2][RLE_BLK];
   __shared__ uint32_t exits[RLE_WARM + 64], ready[RLE_WARM + 64];
