@@ -61,7 +61,7 @@ PHASE_KERNELS = {
     "decompress_stage2_wave": "lz_exec_wave_kernel (LZ77 execution, one wavefront per chunk)",
     "decompress_stage2": {"zstd": "lz_exec_kernel (LZ77 execution, one workgroup per chunk)", "snappy": "lz_exec_tokens_kernel (LZ77 execution, one workgroup per chunk)",
                           "lz4": "lz_exec_tokens_kernel (LZ77 execution, one workgroup per chunk)", "zlib": "decompress_deflate_kernel (one wavefront per chunk)"},
-    "walk": "rle_walk_kernel / rle_walk_short_kernel rounds + scans (run boundaries)",
+    "walk": "decompress_finalize_kernel + rle_walk_kernel / rle_walk_short_kernel rounds + scans (run boundaries)",
     "present": "pres_*_kernel (PRESENT -> validity, ranks)",
     "expand": "rle2_expand_kernel (+ rle1 / byte expand)",
     "finish": "finishers: null spacing, strings, varint / decimal, timestamps",

@@ -397,7 +397,8 @@ int orcgpu_encode_rle2_i64(orcgpu_ctx* ctx, const int64_t* values, uint64_t n, i
  * expansion kernels alone (the dominant kernel), measured with hipEvents on the ctx stream. */
 int orcgpu_last_timing(const orcgpu_ctx* ctx, float* total_ms, float* expand_ms, uint32_t* expand_launches);
 /* The same call split into the phases of the pipeline (HIP events between them, same stream):
- *   0 block decompression (compression.rs:142-195)      1 run-boundary walk + output position scans
+ *   0 block decompression (compression.rs:142-195): the block decoders' kernels
+ *   1 the chunks' plain bytes strung together (Decompressor::read across chunks), run-boundary walk + output position scans
  *   2 PRESENT streams -> validity / ranks               3 RLE expansion (the three *_expand kernels)
  *   4 finishers (null spacing, strings, decimals, timestamps) + the summary copy
  *   5 (part of 0) the first stage of the block decompressors alone: Zstandard entropy decoding / Snappy and LZ4 token parsing;
