@@ -433,6 +433,81 @@ def spawn_ranks(args):
     raise SystemExit(rc)
 
 
+# The kernels a roofline line may name: ONE kernel each, bracketed by HIP events on the stream that launches it (a lane's stream).
+# "walk" / "present" / "finish" are many kernels (and, beside another lane, waits for CU slots): phases, never the dominant kernel.
+ROOF_KERNELS = {
+    "seq": "zstd_seq_quads_kernel (Zstandard FSE sequences, four lanes per block; events around the kernel alone)",
+    "exec": {"zstd": "lz_exec_wave_kernel / lz_exec_kernel (LZ77 execution of Zstandard sequences)", "snappy": "lz_exec_tokens_kernel (LZ77 execution, one workgroup per chunk)",
+             "lz4": "lz_exec_tokens_kernel (LZ77 execution, one workgroup per chunk)", "zlib": "lz_exec_kernel + decompress_deflate_kernel (DEFLATE execution)"},
+    "stage1": {"zstd": "zstd_entropy_kernel (FSE sequences + Huffman literals, one wavefront per block)", "snappy": "lz_parse_kernel (token stage, one workgroup per chunk)",
+               "lz4": "lz_parse_kernel (token stage, one workgroup per chunk)", "zlib": "inflate_parse_kernel (DEFLATE token stage)"},
+    "expand": "rle2_expand_kernel (+ rle1 / byte expand: RLE expansion into the Arrow value buffers)",
+}
+PMC_NAMES = {"seq": "zstd_seq_quads_kernel", "exec": "lz_exec_wave_kernel", "stage1": "zstd_entropy_kernel", "expand": "rle2_expand_kernel"}
+
+
+def pmc_traffic(workload, comp, kernel_key, algo_bytes_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r*_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE in rocprofv3 passes of their own; PMC counters cannot be read inside this process).  The passes may have run at
+    another table size: the kernel's measured bytes per ALGORITHMIC byte are applied to this run's algorithmic bytes per launch.
+    FETCH_SIZE is taken raw (the gfx950 x2 correction applies to wide coalesced reads only: both figures are in the file)."""
+    import glob
+    tag = {"lineitem": "lineitem_" + str(comp), "c3": "c3_" + str(comp), "c2": "c2"}.get(workload)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            w = json.load(open(f))["workloads"].get(tag)
+            k = w["kernels"][PMC_NAMES[kernel_key]]
+            per_algo = (k["FETCH_KB_run"] + k["WRITE_KB_run"]) * 1024.0 / w["decode_calls_in_run"] / w["algorithmic_bytes_per_step"]
+            return int(per_algo * algo_bytes_per_launch), "%s: %s, (FETCH_SIZE raw + WRITE_SIZE) per algorithmic byte of the pass x this run's algorithmic bytes per launch" % (
+                os.path.basename(f), PMC_NAMES[kernel_key])
+        except (KeyError, TypeError, ValueError, ZeroDivisionError, OSError):
+            continue
+    return None, None
+
+
+def roofline_of(lane_acc, comp, workload, step_algo_bytes):
+    """The dominant KERNEL of the step, priced launch by launch: every column lane launches its own instance over its own columns;
+    `achieved` = (sum over the lanes' launches of the algorithmic bytes THAT launch works for: the lane's staged stream bytes in +
+    its Arrow bytes out) / (sum of those launches' durations) = algorithmic bytes per launch / average launch duration."""
+    best = None
+    for key in ("seq", "exec", "stage1", "expand"):
+        if key == "stage1" and any(a["seq"] > 0 for a in lane_acc.values()):
+            continue  # (table scale: the first stage is the table kernel + the sequences kernel, priced as "seq")
+        ls = [a for a in lane_acc.values() if a[key] > 0 and a["steps"]]
+        if not ls:
+            continue
+        ms = sum(a[key] for a in ls)            # summed over lanes and steps
+        by = sum(a["stream_bytes"] + a["arrow_bytes"] for a in ls)
+        launches = sum(a["steps"] for a in ls)
+        if best is None or ms / launches * len(ls) > best[1]:
+            best = (key, ms / launches * len(ls), ms, by, launches, len(ls))
+    if best is None:
+        return {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 0.0, "traffic": None}
+    key, _, ms, by, launches, nl = best
+    name = ROOF_KERNELS[key]
+    if isinstance(name, dict):
+        name = name.get(comp, "block decompression kernel")
+    achieved = by / (ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic(workload, comp, key, by / launches)
+    return {"bound": "hbm", "kernel": name, "phase": key, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
+            "launches_per_step": nl, "algorithmic_bytes_per_launch": int(by / launches), "kernel_ms": round(ms / launches, 4),
+            "kernel_ms_per_step_all_launches": round(ms / launches * nl, 4), "algorithmic_bytes_per_step": step_algo_bytes,
+            "method": "sum over column lanes of (lane's stream bytes in + Arrow bytes out) / sum of the lanes' kernel spans (HIP events on each lane's stream)"}
+
+
+def lanes_of(lane_acc):
+    out = []
+    for l in sorted(lane_acc):
+        a = lane_acc[l]
+        n = max(1, a["steps"])
+        out.append({"lane": l, "stream_bytes": a["stream_bytes"] // n, "arrow_bytes": a["arrow_bytes"] // n, "host_ms_before_first_launch": round(a["start_ms"] / n, 3),
+                    "device_ms": round(a["total_ms"] / n, 3), "zstd_tables_ms": round(a["tables"] / n, 3), "zstd_seq_quads_kernel_ms": round(a["seq"] / n, 3),
+                    "stage1_ms": round(a["stage1"] / n, 3), "exec_kernel_ms": round(a["exec"] / n, 3), "walk_ms": round(a["walk"] / n, 3),
+                    "expand_ms": round(a["expand"] / n, 3), "finish_ms": round(a["finish"] / n, 3)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -535,12 +610,28 @@ def main():
     t0 = time.perf_counter()
     phase = {k: 0.0 for k in capi.Context.PHASES + ("decompress_stage1", "decompress_tables")}
     tot_ms = 0.0
+    lane_acc = {}  # lane -> sums over the timed steps of its kernels' spans and of the bytes its launches worked for
     for _ in range(args.steps):
         if staged:
             ctx.decode(staged, results)
             tot_ms += ctx.timing()[0]
             for k, v in ctx.phase_ms().items():
                 phase[k] += v
+            for ls in ctx.lane_stats():
+                a = lane_acc.setdefault(ls["lane"], {"steps": 0, "stream_bytes": 0, "arrow_bytes": 0, "start_ms": 0.0, "total_ms": 0.0, "seq": 0.0, "exec": 0.0,
+                                                     "stage1": 0.0, "tables": 0.0, "expand": 0.0, "walk": 0.0, "finish": 0.0})
+                a["steps"] += 1
+                a["stream_bytes"] += ls["stream_bytes"]
+                a["arrow_bytes"] += ls["arrow_bytes"]
+                a["start_ms"] += ls["start_ms"]
+                a["total_ms"] += ls["total_ms"]
+                a["seq"] += ls["seq_kernel_ms"]
+                a["exec"] += ls["exec_kernel_ms"]
+                a["stage1"] += ls["phase_ms"]["decompress_stage1"]
+                a["tables"] += ls["phase_ms"]["decompress_tables"]
+                a["expand"] += ls["phase_ms"]["expand"]
+                a["walk"] += ls["phase_ms"]["walk"]
+                a["finish"] += ls["phase_ms"]["finish"]
     torch.cuda.synchronize()
     my_dt = time.perf_counter() - t0
     barrier()
@@ -582,21 +673,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = total_arrow / (dt / args.steps) / 1e9
     phase = {k: v / args.steps for k, v in phase.items()}
-    dom = max(capi.Context.PHASES, key=lambda k: phase[k]) if staged else "expand"
-    dom_ms = phase[dom]
-    dom_kernel = PHASE_KERNELS[dom]
-    if dom == "decompress":
-        # the phase is two kernels back to back: the dominant KERNEL is the longer one (an event sits between them)
-        s1, s2 = phase["decompress_stage1"], phase["decompress"] - phase["decompress_stage1"]
-        dom, dom_ms = ("decompress_stage1", s1) if s1 >= s2 else ("decompress_stage2", s2)
-        dom_kernel = PHASE_KERNELS[dom].get(comp, PHASE_KERNELS["decompress"])
-        if comp == "zstd" and phase["decompress_tables"] > 0:
-            # table scale: the first stage is the FSE table kernel, then the sequences kernel (an event sits between them); the
-            # execution stage is lz_exec_wave_kernel
-            sq = s1 - phase["decompress_tables"]
-            dom, dom_ms, dom_kernel = ("decompress_sequences", sq, PHASE_KERNELS["decompress_sequences"]) if sq >= s2 else ("decompress_stage2", s2, PHASE_KERNELS["decompress_stage2_wave"])
-    algo_bytes = stream_bytes + arrow_bytes  # staged stream bytes in + Arrow bytes out (this rank's launch)
-    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roof = roofline_of(lane_acc, comp, args.workload, stream_bytes + arrow_bytes)
     e2e_dt, e2e_bytes = pipelined_end_to_end(ctx, stripes, comp) if len(stripes) >= 2 and not args.no_e2e else (0.0, 0)
     h2d = stream_bytes / t_stage / 1e9 if t_stage > 0 else None
     d2h = fetch_bytes / t_fetch / 1e9 if t_fetch > 0 and fetch_bytes else None
@@ -624,10 +701,8 @@ def main():
         "end_to_end_ms_per_stripe": round(e2e_dt / len(stripes) * 1e3, 3) if e2e_dt > 0 else None,
         "setup": {"generate_s": round(plan["gen_s"], 2), "generate_procs": plan["gen_procs"], "check_s": round(t_check, 2),
                   "checked": "skipped" if args.skip_check else ("first stripe buffer by buffer + every stripe by whole-buffer sums" if args.workload == "lineitem" else "every stripe buffer by buffer")},
-        "roofline": {"bound": "hbm", "kernel": dom_kernel, "phase": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
-                     "kernel_ms": round(dom_ms, 4),
-                     "whole_step_frac": round(algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)},
+        "roofline": dict(roof, whole_step_frac=round((stream_bytes + arrow_bytes) / (my_dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)),
+        "lanes": lanes_of(lane_acc),
     }
     if per_rank is not None:
         out["per_rank"] = per_rank

@@ -409,6 +409,29 @@ int orcgpu_last_timing(const orcgpu_ctx* ctx, float* total_ms, float* expand_ms,
 #define ORCGPU_N_PHASES 7
 int orcgpu_last_phase_ms(const orcgpu_ctx* ctx, float* ms, uint32_t n);
 
+/* A decode call may run its columns as up to four COLUMN LANES side by side (each lane: a HIP stream of its own with the whole
+ * pipeline over its share of the columns; the planner decides, ORCGPU_LANES = 1..4 forces a count -- read at every call).
+ * Every lane launches its own kernels over its own bytes: a kernel's roofline figure must be priced launch by launch, with the
+ * bytes THAT launch works for.  orcgpu_last_lane_stats reports lane `lane` of the last orcgpu_decode_staged call on `ctx`:
+ *   n_lanes        lanes that call ran (the same in every lane's record)
+ *   stream_bytes   staged (compressed) stream bytes of the columns the lane decoded      } SURVEY 8(d)'s algorithmic bytes
+ *   arrow_bytes    Arrow bytes it left in the results                                     } of the lane's launches
+ *   start_ms       host milliseconds from the call's entry to the lane's first launch (planning, sorting, table set-up)
+ *   total_ms       first launch to the end of the lane's last kernel (HIP events on the lane's stream)
+ *   phase_ms[]     the phases of orcgpu_last_phase_ms, for this lane
+ *   seq_kernel_ms  Zstandard at table scale: zstd_seq_quads_kernel alone (an event in front of it and one behind it, in front of
+ *                  the wait for the literals kernel that runs beside it); 0 when the call had no such launch
+ *   exec_kernel_ms the LZ77 execution kernel(s) of the lane (lz_exec_wave_kernel / lz_exec_kernel / lz_exec_tokens_kernel)
+ * Returns ORCGPU_INVALID_ARGUMENT for a lane the last call did not run. */
+typedef struct orcgpu_lane_stats {
+  uint32_t lane, n_lanes;
+  uint64_t stream_bytes, arrow_bytes;
+  float start_ms, total_ms;
+  float phase_ms[ORCGPU_N_PHASES];
+  float seq_kernel_ms, exec_kernel_ms;
+} orcgpu_lane_stats;
+int orcgpu_last_lane_stats(const orcgpu_ctx* ctx, uint32_t lane, orcgpu_lane_stats* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ EXPORTS = [
     "orcgpu_open", "orcgpu_close", "orcgpu_last_error", "orcgpu_version", "orcgpu_stage_stripe", "orcgpu_staged_free",
     "orcgpu_staged_bytes", "orcgpu_decode_staged", "orcgpu_stripe_decode", "orcgpu_result_free", "orcgpu_result_status",
     "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
-    "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_fetch_async", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_timezone_offsets", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms", "orcgpu_encode_rle2_i64",
+    "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_fetch_async", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_timezone_offsets", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms", "orcgpu_last_lane_stats", "orcgpu_encode_rle2_i64",
     "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
     "orcgpu_reader_set_projection", "orcgpu_reader_set_projection_roots", "orcgpu_reader_set_schema", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_shard", "orcgpu_shard_columns", "orcgpu_reader_column_weight", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection", "orcgpu_reader_set_prefetch",
     "orcgpu_reader_set_row_group_pruning", "orcgpu_reader_row_groups", "orcgpu_index_entry", "orcgpu_reader_set_predicate",
@@ -55,6 +55,12 @@ class StripeDesc(C.Structure):
     _fields_ = [("n_rows", C.c_uint64), ("compression", C.c_int32), ("block_size", C.c_uint64), ("ts_base_seconds", C.c_int64),
                 ("batch_size", C.c_uint32), ("n_streams", C.c_uint32), ("streams", C.POINTER(Stream)), ("n_columns", C.c_uint32),
                 ("columns", C.POINTER(Column)), ("writer_timezone", C.c_char_p)]
+
+
+class LaneStats(C.Structure):
+    _fields_ = [("lane", C.c_uint32), ("n_lanes", C.c_uint32), ("stream_bytes", C.c_uint64), ("arrow_bytes", C.c_uint64),
+                ("start_ms", C.c_float), ("total_ms", C.c_float), ("phase_ms", C.c_float * 7), ("seq_kernel_ms", C.c_float),
+                ("exec_kernel_ms", C.c_float)]
 
 
 class RowSelector(C.Structure):
@@ -164,6 +170,7 @@ def load():
     L.orcgpu_result_export_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.orcgpu_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.orcgpu_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
+    L.orcgpu_last_lane_stats.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(LaneStats)]
     L.orcgpu_encode_rle2_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.orcgpu_reader_open_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
     L.orcgpu_reader_open_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]
@@ -281,6 +288,24 @@ class Context:
         a = (C.c_float * 7)()
         self.L.orcgpu_last_phase_ms(self.h, a, 7)
         return dict(zip(self.PHASES + ("decompress_stage1", "decompress_tables"), [float(x) for x in a]))
+
+    def lane_stats(self):
+        """Every column lane of the last decode call (orcgpu_last_lane_stats): [{lane, n_lanes, stream_bytes, arrow_bytes,
+        start_ms, total_ms, phase_ms{}, seq_kernel_ms, exec_kernel_ms}] -- a lane's launches and the bytes they worked for."""
+        out = []
+        k = 0
+        while True:
+            st = LaneStats()
+            if self.L.orcgpu_last_lane_stats(self.h, k, C.byref(st)) != OK:
+                break
+            out.append({"lane": st.lane, "n_lanes": st.n_lanes, "stream_bytes": int(st.stream_bytes), "arrow_bytes": int(st.arrow_bytes),
+                        "start_ms": float(st.start_ms), "total_ms": float(st.total_ms),
+                        "phase_ms": dict(zip(self.PHASES + ("decompress_stage1", "decompress_tables"), [float(x) for x in st.phase_ms])),
+                        "seq_kernel_ms": float(st.seq_kernel_ms), "exec_kernel_ms": float(st.exec_kernel_ms)})
+            k += 1
+            if k >= st.n_lanes:
+                break
+        return out
 
 
 class Staged:

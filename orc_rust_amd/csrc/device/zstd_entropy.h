@@ -41,6 +41,19 @@ struct ZSeqHdr {      // written by zstd_entropy_kernel (tables mode) per block 
   uint32_t status;    // nonzero: a table description is broken (the code zstd_entropy_kernel would report)
   uint32_t pad;
 };
+// A sequence as zstd_seq_quads_kernel leaves it for the execution kernel: 8 bytes {offset value : 29, match length : 18, literal
+// length : 17}.  Match lengths end at 65 539 + 65 535, literal lengths at 65 536 + 65 535 (RFC 8878 3.1.1.3.2.1.1); an offset
+// value of 2^29 or more cannot be met by any chunk (a chunk header holds 23 bits of length, a plain chunk is bounded by the
+// block size): it is kept as 2^29 - 1, which the execution kernel rejects like every offset that reaches before the frame.
+__device__ __forceinline__ uint2 zseq_pack(uint32_t ofv, uint32_t ml, uint32_t ll) {
+  const uint32_t o = ofv < 0x1fffffffu ? ofv : 0x1fffffffu;
+  return make_uint2(o | ml << 29, ml >> 3 | ll << 15);
+}
+__device__ __forceinline__ void zseq_unpack(uint2 p, uint32_t& ofv, uint32_t& ml, uint32_t& ll) {
+  ofv = p.x & 0x1fffffffu;
+  ml = p.x >> 29 | (p.y & 0x7fffu) << 3;
+  ll = p.y >> 15;
+}
 #define ZL_CELLS 1280u  // cells per block: LL [0, 512), ML [512, 1024), OF [1024, 1280)
 #define ZL_LL 0u
 #define ZL_ML 512u
@@ -531,7 +544,7 @@ __device__ __forceinline__ int zstd_literals_job(LDS& L, const ZBlock& B, const 
     int bad = 0;
     const uint32_t regen = B.lit_regen;
     if (B.lit_streams == 1) {
-      bad = huf_decode_par(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true);
+      bad = huf_decode_par(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true PROF_ARG);
     } else {
       if (qn < 6) st = 13;
       else {
@@ -547,7 +560,7 @@ __device__ __forceinline__ int zstd_literals_job(LDS& L, const ZBlock& B, const 
             const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
             const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
             const uint32_t on = k < 3 ? seg : regen - 3 * seg;
-            bad = huf_decode_par(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true);
+            bad = huf_decode_par(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true PROF_ARG);
           }
         }
       }

@@ -244,12 +244,15 @@ struct orcgpu_ctx {
   size_t pinned_cap = 0;
   uint8_t* fin_pinned = nullptr;       // staging of the finishers' job table
   size_t fin_pinned_cap = 0;
-  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk, after the decompressors' first stage, in front of the Zstandard sequences kernel (one lane per block)
+  hipEvent_t ev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk, after the decompressors' first stage, in front of the Zstandard sequences kernel (one lane per block), behind it
   uint32_t n_cus = 0;
   hipStream_t aux_stream = nullptr;   // the Zstandard execution kernel runs here, beside the entropy kernel on `stream`
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
   float last_total_ms = 0, last_expand_ms = 0;
   float last_phase_ms[ORCGPU_N_PHASES] = {0, 0, 0, 0, 0, 0, 0};
+  orcgpu_lane_stats last_stats{};     // this lane's part of the last call (orcgpu_last_lane_stats)
+  uint32_t last_n_lanes = 1;          // lane 0: lanes the last call ran
+  double call_t0 = 0;                 // host clock (us) when the call that drives this lane was entered
   uint32_t last_expand_launches = 0;
   // ---- staging pipeline (lane 0 only): a copy stream, two pinned pieces filled by a few host threads while the other one
   // is on its way to HBM, a pool of stripe arenas ----
@@ -695,6 +698,14 @@ struct Plan {
 };
 
 }  // namespace
+
+// The decoder runs its column lanes, the Zstandard literals kernel and the copies back on HIP streams of their own.  The runtime
+// maps streams onto 4 hardware queues unless told otherwise, and kernels that share a queue run one after the other whatever their
+// streams (measured: the literals kernel ran beside the sequences kernel only with more queues).  The setting is read when the HIP
+// runtime initialises, i.e. at the first HIP call of the process: the library asks for 8 when it is loaded, unless the host has
+// chosen a value itself.  A host that has touched HIP before loading the library must export GPU_MAX_HW_QUEUES=8 itself
+// (INTEGRATION.md); results do not depend on it, only how much of a call runs side by side.
+__attribute__((constructor)) static void orcgpu_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 // =================================================================================================
 extern "C" {

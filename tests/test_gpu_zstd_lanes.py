@@ -113,3 +113,78 @@ def test_corrupted_sequence_sections_fail_like_the_oracle(lanes):
             G.assert_column_parity(res, 0, c, st, n, 8192, compression="zstd", block_size=65536, what=("lanes corrupt", lanes, trial, pos))
         finally:
             res.free()
+
+
+# ---- the path bench.py's headline takes: several COLUMN LANES and the table-scale kernels together -------------------------
+# (the planner takes it by itself only from 64 MiB staged / 40 M sequences on; ORCGPU_LANES is read at every call)
+@pytest.mark.parametrize("n_lanes", [2, 3, 4])
+def test_column_lanes_with_the_table_scale_kernels(monkeypatch, n_lanes):
+    """Two lineitem stripes in ONE call, split over 2 / 3 / 4 column lanes, every lane through zstd_literals_kernel, the FSE table
+    kernel, zstd_seq_quads_kernel (8-byte sequence records) and lz_exec_wave_kernel: every column of both stripes against the
+    oracle, batch by batch, and against what the generator implies; the lanes' statistics add up to the call."""
+    monkeypatch.setenv("ORCGPU_ZSTD_LANES", "1")
+    monkeypatch.setenv("ORCGPU_LANES", str(n_lanes))
+    rows = 260_000
+    table = W.lineitem_table(rows)
+    stripes = [W.lineitem_stripe(table, 0, 150_000, "zstd"), W.lineitem_stripe(table, 150_000, rows, "zstd")]
+    c = G.ctx()
+    staged = [c.stage(n, streams, cols, compression="zstd") for n, cols, streams, _ in stripes]
+    results = c.decode(staged)
+    stats = c.lane_stats()
+    assert len(stats) == n_lanes and all(s["n_lanes"] == n_lanes for s in stats), stats
+    assert sum(s["stream_bytes"] for s in stats) == sum(s.nbytes() for s in staged)
+    assert sum(s["arrow_bytes"] for s in stats) == sum(r.arrow_bytes for r in results)
+    assert all(s["seq_kernel_ms"] > 0 and s["exec_kernel_ms"] > 0 for s in stats), stats  # every lane ran the table-scale kernels
+    for s in staged:
+        s.free()
+    for (n, cols, streams, expect), res in zip(stripes, results):
+        assert res.status()[0] == 0, res.status()
+        W.check_result(res, cols, expect)
+        for ci, cc in enumerate(cols):
+            G.assert_column_parity(res, ci, cc, streams, n, 8192, compression="zstd", what=("lanes x table scale", n_lanes, cc["name"]))
+        res.free()
+
+
+def test_lane_count_does_not_change_a_byte(monkeypatch):
+    """The same stripe through 1, 2 and 3 lanes, table-scale kernels on and off: identical Arrow buffers."""
+    rows = 120_000
+    table = W.lineitem_table(rows)
+    n, cols, streams, expect = W.lineitem_stripe(table, 0, rows, "zstd")
+    ref = None
+    for zl in ("0", "1"):
+        for nl in ("1", "2", "3"):
+            monkeypatch.setenv("ORCGPU_ZSTD_LANES", zl)
+            monkeypatch.setenv("ORCGPU_LANES", nl)
+            res = G.gpu_decode(n, cols, streams, compression="zstd")
+            assert res.status()[0] == 0, (zl, nl, res.status())
+            got = [[res.batch(b, ci) for ci in range(len(cols))] for b in range(res.n_batches)]
+            res.free()
+            if ref is None:
+                ref = got
+                continue
+            for b, (rb, gb) in enumerate(zip(ref, got)):
+                for ci, (r1, g1) in enumerate(zip(rb, gb)):
+                    assert r1["values"] == g1["values"] and r1["validity"] == g1["validity"] and r1["null_count"] == g1["null_count"], (zl, nl, b, cols[ci]["name"])
+                    assert (r1["offsets"] is None) == (g1["offsets"] is None) and (r1["offsets"] is None or np.array_equal(r1["offsets"], g1["offsets"])), (zl, nl, b, ci)
+
+
+def test_offset_values_beyond_the_record_format_are_rejected(lanes):
+    """zseq_pack keeps 29 bits of an offset value: a sequence whose offset code says 2^30 is a corrupt chunk for the oracle (the
+    match reaches before the frame) and for the GPU path (the record holds 2^29 - 1: just as far out of reach)."""
+    # a Compressed_Block by hand: raw literals "abcd", ONE sequence {ll 4, ml 3, offset code 30 with 30 zero extra bits}; all three
+    # tables in RLE_Mode (one symbol each, no state bits): the bit stream is the extra bits alone + the closing 1 bit
+    lit = b"abcd"
+    seq = bytes([1, 0b01010100, 4, 30, 0])  # 1 sequence; modes LL=RLE, OF=RLE, ML=RLE; symbols LL 4, OF 30, ML 0
+    bits = bytes([0, 0, 0, 0b01000000])     # 30 extra bits of the offset (zero), then the final-bit marker
+    body = bytes([len(lit) << 3]) + lit + seq + bits
+    bh = (len(body) << 3) | (2 << 1) | 1
+    frame_bytes = b"\x28\xb5\x2f\xfd" + bytes([0x20, 7]) + bytes([bh & 255, (bh >> 8) & 255, bh >> 16]) + body  # single segment, content size 7
+    chunk = bytes([(len(frame_bytes) << 1) & 255, (len(frame_bytes) >> 7) & 255, (len(frame_bytes) >> 15) & 255]) + frame_bytes
+    c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+    st = [(1, DATA, np.frombuffer(chunk, dtype=np.uint8))]
+    res = G.gpu_decode(1, [c], st, compression="zstd", block_size=65536)
+    try:
+        assert res.status()[0] != 0
+        G.assert_column_parity(res, 0, c, st, 1, 8192, compression="zstd", block_size=65536, what=("offset code 30", lanes))
+    finally:
+        res.free()
