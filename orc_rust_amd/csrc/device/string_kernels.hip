@@ -646,15 +646,25 @@ __device__ __forceinline__ __int128 decimal_rescale(__int128 v, uint32_t vs, uin
 __device__ __forceinline__ void varint_decode128_body(const uint8_t* s, const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx,
                                                                            const unsigned long long* tmask, const uint32_t* trank, __int128* dense,
                                                                            uint64_t n_upper, unsigned long long* err, const int32_t* scales, uint32_t fixed_scale) {
+  // The values of a workgroup's 2 KiB of stream are one contiguous run of the output: they are gathered in LDS and leave as
+  // consecutive 16-byte stores.  (Stored from the thread that decodes them -- its two to four values at a lane stride of 32 to 64
+  // bytes, one value per instruction -- every instruction wrote a quarter to a half of each 64-byte line it touched: 2.5 x the
+  // output in HBM writes by the counters.)
+  __shared__ __attribute__((aligned(16))) __int128 stage[2048];  // (2048 stream bytes end 2048 values at the very most)
+  __shared__ uint32_t stage_n;
+  if (threadIdx.x == 0) stage_n = 0;
+  __syncthreads();
   const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
   uint64_t len = scalars[len_idx];
   if (len > n_upper) len = n_upper;
-  if (p0 >= len) return;
+  const uint64_t needed = scalars[needed_idx];
+  const uint64_t wg0 = (uint64_t)blockIdx.x * 2048;  // (a multiple of 64: the rank word itself)
+  const uint64_t k0 = wg0 < len ? (uint64_t)trank[wg0 >> 6] : 0;
+  if (p0 < len) {
   const unsigned long long m = tmask[p0 >> 6];
   const uint32_t sh = (uint32_t)p0 & 63;
   uint32_t mb = (uint32_t)(m >> sh) & 0xffu;  // (bits at and behind `len` are clear: varint_terms_body)
   uint64_t k = (uint64_t)trank[p0 >> 6] + __builtin_popcountll(m & ((1ull << sh) - 1));
-  const uint64_t needed = scalars[needed_idx];
   if (len - p0 <= 8 && !((mb >> (len - 1 - p0)) & 1)) {
     // an unterminated tail: the stream ends inside a varint
     const uint64_t p = len - 1, kt = k + __builtin_popcount(mb);
@@ -664,9 +674,11 @@ __device__ __forceinline__ void varint_decode128_body(const uint8_t* s, const ui
       report_err64(err, kt, run >= 20 ? ORC_E_VARINT : ORC_E_IO);
     }
   }
-  if (!mb || k >= needed) return;
+  if (mb && k < needed) {
   const uint64_t own = ld_u64(s + p0), prev = p0 ? ld_u64(s + p0 - 8) : 0;
+  uint64_t kend = k;
   for (; mb && k < needed; mb &= mb - 1, k++) {
+    kend = k + 1;
     const uint32_t j = (uint32_t)__builtin_ctz(mb);
     const uint64_t p = p0 + j;
     if (p >= 7) {
@@ -686,7 +698,7 @@ __device__ __forceinline__ void varint_decode128_body(const uint8_t* s, const ui
         u |= (v >> 6) & (0x7full << 42);
         // (bytes behind the terminator do not exist in v: the shift brought zeros in; the terminator's own flag is clear)
         const int64_t z = (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
-        dense[k] = scales ? decimal_rescale((__int128)z, (uint32_t)scales[k], fixed_scale) : (__int128)z;
+        stage[k - k0] = scales ? decimal_rescale((__int128)z, (uint32_t)scales[k], fixed_scale) : (__int128)z;
         if (p == len - 1 && k + 1 < needed) report_err64(err, k + 1, ORC_E_IO);
         continue;
       }
@@ -696,17 +708,23 @@ __device__ __forceinline__ void varint_decode128_body(const uint8_t* s, const ui
     uint32_t nb = (uint32_t)(p - start + 1);
     if (nb > 19) {  // byte index 19 has offset 133 >= 128: checked_shl fails (VarintTooLarge)
       report_err64(err, k, ORC_E_VARINT);
+      stage[k - k0] = 0;  // (never read by a consumer: the column fails at this value)
       continue;
     }
     unsigned __int128 u = 0;
     for (uint32_t i = 0; i < nb; i++) u |= (unsigned __int128)(s[start + i] & 0x7f) << (7 * i);
     unsigned __int128 z = (u >> 1) ^ (unsigned __int128)(-(__int128)(u & 1));
-    dense[k] = scales ? decimal_rescale((__int128)z, (uint32_t)scales[k], fixed_scale) : (__int128)z;
+    stage[k - k0] = scales ? decimal_rescale((__int128)z, (uint32_t)scales[k], fixed_scale) : (__int128)z;
     // "not enough values": the last terminator knows how many values exist
     if (p == len - 1 && k + 1 < needed) report_err64(err, k + 1, ORC_E_IO);
   }
+  atomicMax(&stage_n, (uint32_t)(kend - k0));
+  }
+  }
+  __syncthreads();
+  const uint32_t nv = stage_n;
+  for (uint32_t i = threadIdx.x; i < nv; i += 256) dense[k0 + i] = stage[i];
 }
-// empty DATA stream with values needed
 __device__ __forceinline__ void varint_empty_check_body(const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx, unsigned long long* err) {
   if (threadIdx.x == 0 && scalars[len_idx] == 0 && scalars[needed_idx] > 0) report_err64(err, 0, ORC_E_IO);
 }
