@@ -407,7 +407,7 @@ long oo_lzo1x(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
 }
 
 /* ------------------------------------------------------------------------------------------
- * RFC 8878 Zstandard frame (no dictionary; content checksum skipped, not verified)
+ * RFC 8878 Zstandard frame (no dictionary; the content checksum, when the frame flags one, is verified)
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
   const uint8_t* p;
@@ -897,6 +897,57 @@ done:
   return ret;
 }
 
+/* XXH64 (seed 0) of the frame's regenerated content: RFC 8878 3.1.1 Content_Checksum = its low 32 bits.  libzstd behind the
+ * reference's zstd crate (src/compression.rs:151-159) verifies it when the frame header flags one; a mismatch fails the
+ * decoder.  The algorithm is the published xxHash specification (four 64-bit lanes over 32-byte stripes, then the tail). */
+#define XXP1 0x9E3779B185EBCA87ull
+#define XXP2 0xC2B2AE3D27D4EB4Full
+#define XXP3 0x165667B19E3779F9ull
+#define XXP4 0x85EBCA77C2B2AE63ull
+#define XXP5 0x27D4EB2F165667C5ull
+static uint64_t xx_rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static uint64_t xx_rd64(const uint8_t* p) {
+  uint64_t v = 0;
+  for (int i = 0; i < 8; i++) v |= (uint64_t)p[i] << (8 * i);
+  return v;
+}
+static uint64_t xx_round(uint64_t acc, uint64_t in) { return xx_rotl(acc + in * XXP2, 31) * XXP1; }
+static uint64_t xx_merge(uint64_t h, uint64_t v) { return (h ^ xx_round(0, v)) * XXP1 + XXP4; }
+uint64_t oo_xxh64(const uint8_t* p, size_t n) {
+  const uint8_t* end = p + n;
+  uint64_t h;
+  if (n >= 32) {
+    uint64_t v1 = XXP1 + XXP2, v2 = XXP2, v3 = 0, v4 = 0 - XXP1;
+    for (; p + 32 <= end; p += 32) {
+      v1 = xx_round(v1, xx_rd64(p));
+      v2 = xx_round(v2, xx_rd64(p + 8));
+      v3 = xx_round(v3, xx_rd64(p + 16));
+      v4 = xx_round(v4, xx_rd64(p + 24));
+    }
+    h = xx_rotl(v1, 1) + xx_rotl(v2, 7) + xx_rotl(v3, 12) + xx_rotl(v4, 18);
+    h = xx_merge(h, v1);
+    h = xx_merge(h, v2);
+    h = xx_merge(h, v3);
+    h = xx_merge(h, v4);
+  } else {
+    h = XXP5;
+  }
+  h += (uint64_t)n;
+  for (; p + 8 <= end; p += 8) h = xx_rotl(h ^ xx_round(0, xx_rd64(p)), 27) * XXP1 + XXP4;
+  if (p + 4 <= end) {
+    uint64_t k = (uint64_t)p[0] | (uint64_t)p[1] << 8 | (uint64_t)p[2] << 16 | (uint64_t)p[3] << 24;
+    h = xx_rotl(h ^ k * XXP1, 23) * XXP2 + XXP3;
+    p += 4;
+  }
+  for (; p < end; p++) h = xx_rotl(h ^ *p * XXP5, 11) * XXP1;
+  h ^= h >> 33;
+  h *= XXP2;
+  h ^= h >> 29;
+  h *= XXP3;
+  h ^= h >> 32;
+  return h;
+}
+
 long oo_zstd_frame(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
   size_t pos = 0, out = 0;
   /* the zstd crate's streaming Decoder reads concatenated frames until EOF */
@@ -989,7 +1040,9 @@ long oo_zstd_frame(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
     if (fcs_bytes && (uint64_t)(out - frame_start) != fcs) return -1;
     if (has_ck) {
       if (pos + 4 > n) return -1;
-      pos += 4; /* XXH64 low 32 bits: not verified by this oracle */
+      uint32_t want = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16) | ((uint32_t)src[pos + 3] << 24);
+      if ((uint32_t)oo_xxh64(dst + frame_start, out - frame_start) != want) return -1; /* ZSTD_error_checksum_wrong */
+      pos += 4;
     }
   }
   return (long)out;

@@ -50,7 +50,8 @@ long oo_inflate_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
 long oo_snappy_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
 long oo_lz4_block(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
 long oo_lzo1x(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);     /* LZO1X, as lzokay_native::decompress_all (compression.rs:174-183) */
-long oo_zstd_frame(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+long oo_zstd_frame(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);   /* a frame's content checksum (XXH64, low 32 bits) is verified when flagged */
+uint64_t oo_xxh64(const uint8_t* p, size_t n);                               /* XXH64, seed 0 */
 
 /* compression.rs:113-123 : returns length, *is_original set */
 uint32_t oo_decode_chunk_header(const uint8_t b[3], int* is_original);

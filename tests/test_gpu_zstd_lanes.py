@@ -188,3 +188,34 @@ def test_offset_values_beyond_the_record_format_are_rejected(lanes):
         G.assert_column_parity(res, 0, c, st, 1, 8192, compression="zstd", block_size=65536, what=("offset code 30", lanes))
     finally:
         res.free()
+
+
+# ---- content checksums (RFC 8878 3.1.1: XXH64 of the frame's content, low 32 bits) ------------------------------------------
+@pytest.mark.parametrize("table_scale", ["0", "1"])
+def test_content_checksums_are_verified(monkeypatch, table_scale):
+    """libzstd behind the reference's zstd crate verifies a frame's checksum when the header flags one (compression.rs:151-159):
+    frames carrying the right checksum decode to the oracle's bytes; ONE chunk with a wrong checksum fails its batch like the
+    oracle (BuildDecoder), and the batches before it are intact.  Both Zstandard paths (one wavefront / one lane per block)."""
+    from test_oracle_codecs import with_checksum
+    import pyarrow as pa
+    monkeypatch.setenv("ORCGPU_ZSTD_LANES", table_scale)
+    block = 65536
+    cd = pa.Codec("zstd")
+    for name, raw in shapes(5).items():
+        raw = raw[:block * 5 + 1234]
+        for bad_chunk in (None, 0, 3):
+            def comp(blk, state={"k": 0}):
+                k = state["k"]
+                state["k"] += 1
+                c = cd.compress(blk, asbytes=True)
+                return with_checksum(c, blk, wrong=(bad_chunk is not None and k == bad_chunk))
+            st = [(1, DATA, frame(raw, comp, block))]
+            c = {"column_id": 1, "orc_type": DOUBLE, "encoding": 0}
+            n = len(raw) // 8
+            res = G.gpu_decode(n, [c], st, compression="zstd", block_size=block)
+            try:
+                if bad_chunk is None:
+                    assert res.status()[0] == 0, (name, res.status())
+                G.assert_column_parity(res, 0, c, st, n, 8192, compression="zstd", block_size=block, what=("checksum", table_scale, name, bad_chunk))
+            finally:
+                res.free()

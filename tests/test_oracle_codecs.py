@@ -114,3 +114,38 @@ def test_lzo1x_round_trips_and_rejections():
     want += b"XY"
     want += want[len(want) - 7:len(want) - 7 + 2]
     assert d == 2062 and O.codec("lzo", bytes(s), len(want) + 16) == bytes(want)
+
+
+def with_checksum(frame, content, wrong=False):
+    """A Zstandard frame as the encoder made it (no checksum) -> the same frame with Content_Checksum_Flag set and the
+    low 32 bits of XXH64(content, seed 0) behind its last block (RFC 8878 3.1.1)."""
+    import xxhash
+    assert frame[:4] == b"\x28\xb5\x2f\xfd" and not frame[4] & 4
+    ck = xxhash.xxh64(content, seed=0).intdigest() & 0xffffffff
+    if wrong:
+        ck ^= 0x00010000
+    return frame[:4] + bytes([frame[4] | 4]) + frame[5:] + ck.to_bytes(4, "little")
+
+
+def test_xxh64_and_the_zstandard_content_checksum():
+    """libzstd (behind the reference's zstd crate, compression.rs:151-159) verifies a frame's content checksum when the header
+    flags one: the oracle's XXH64 against the xxhash package, a flagged frame with the right checksum decodes, a wrong one fails."""
+    import ctypes as C
+    import xxhash
+    L = O.lib()
+    L.oo_xxh64.restype = C.c_uint64
+    L.oo_xxh64.argtypes = [C.c_char_p, C.c_size_t]
+    rng = np.random.default_rng(3)
+    for n in list(range(0, 70)) + [255, 256, 257, 4095, 65536, 100003]:
+        b = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        assert L.oo_xxh64(b, n) == xxhash.xxh64(b, seed=0).intdigest(), n
+    for data in corpora():
+        if not data:
+            continue
+        comp = pa.Codec("zstd").compress(data, asbytes=True)
+        assert O.codec("zstd", with_checksum(comp, data), len(data) + 16) == data
+        assert O.codec("zstd", with_checksum(comp, data, wrong=True), len(data) + 16) is None
+        # two frames in one chunk, the second one's checksum wrong: the chunk fails
+        two = with_checksum(comp, data) + with_checksum(comp, data, wrong=True)
+        assert O.codec("zstd", with_checksum(comp, data) * 2, 2 * len(data) + 16) == data * 2
+        assert O.codec("zstd", two, 2 * len(data) + 16) is None
