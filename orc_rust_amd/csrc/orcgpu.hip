@@ -586,8 +586,11 @@ bool is_string_type(int t) { return t == ORCGPU_T_STRING || t == ORCGPU_T_VARCHA
 
 // ---- per-call plan ------------------------------------------------------------------------------
 // (JC_PRESENT1 + d - 1: PRESENT streams of the fields of Structs / arms of Unions at depth d: they are as long as their parent has non-null rows)
-// kMaxStructDepth classes of them: as deep as the file reader follows a type tree (reader_build: 8 levels below a root column)
-constexpr int kMaxStructDepth = 8;
+// kMaxStructDepth classes of them: the reference recurses without a limit (array_decoder/mod.rs:464-505); here the depth is bounded
+// by a number no schema reaches (the type tree of a file is walked recursively on the host: kMaxTypeDepth below), and the PRESENT
+// phase loops over the depths a call really has
+constexpr int kMaxStructDepth = 256;
+constexpr int kMaxTypeDepth = 256;  // nesting of any kind (Struct / List / Map / Union) the file reader follows below a root column
 enum JobClass { JC_PRESENT = 0, JC_RLE2 = 1, JC_RLE1 = 2, JC_BYTE = 3, JC_PRESENT1 = 4, JC_COUNT = JC_PRESENT1 + kMaxStructDepth };
 
 struct JobPlan {

@@ -111,18 +111,20 @@ def test_row_selection_over_struct_columns(tmp_path):
         assert got.column(name).combine_chunks().equals(exp.column(name).combine_chunks()), name
 
 
-def test_structs_nested_six_deep(tmp_path):
-    """struct_decoder.rs builds field decoders recursively, to any depth; here the PRESENT phase runs once per depth (eight
-    levels: as far as the reader follows a type tree).  Nulls at every level, a string and a List at the bottom."""
-    n = 20_000
+@pytest.mark.parametrize("deep", [6, 14])
+def test_structs_nested_six_deep(tmp_path, deep):
+    """struct_decoder.rs builds field decoders recursively, to any depth; here the PRESENT phase runs once per depth the call has
+    (six levels, and fourteen: deeper than the eight the reader used to follow).  Nulls at every level, a string and a List at the
+    bottom."""
+    n = 20_000 if deep == 6 else 6_000
     rng = np.random.default_rng(21)
     def level(depth):
-        if depth == 6:
+        if depth == deep:
             return {"v": int(rng.integers(-1000, 1000)) if rng.random() > 0.1 else None, "s": "x" * int(rng.integers(0, 5)),
                     "l": None if rng.random() < 0.1 else [int(rng.integers(0, 9)) for _ in range(int(rng.integers(0, 3)))]}
-        return None if rng.random() < 0.12 else {"k%d" % depth: level(depth + 1), "n%d" % depth: depth if rng.random() > 0.2 else None}
+        return None if rng.random() < (0.12 if deep == 6 else 0.05) else {"k%d" % depth: level(depth + 1), "n%d" % depth: depth if rng.random() > 0.2 else None}
     typ = pa.struct([("v", pa.int64()), ("s", pa.string()), ("l", pa.list_(pa.int32()))])
-    for depth in range(5, 0, -1):
+    for depth in range(deep - 1, 0, -1):
         typ = pa.struct([("k%d" % depth, typ), ("n%d" % depth, pa.int32())])
     t = pa.table({"id": pa.array(np.arange(n)), "deep": pa.array([level(1) for _ in range(n)], type=typ)})
     path = str(tmp_path / "deep.orc")
