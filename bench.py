@@ -442,8 +442,11 @@ ROOF_KERNELS = {
     "stage1": {"zstd": "zstd_entropy_kernel (FSE sequences + Huffman literals, one wavefront per block)", "snappy": "lz_parse_kernel (token stage, one workgroup per chunk)",
                "lz4": "lz_parse_kernel (token stage, one workgroup per chunk)", "zlib": "inflate_parse_kernel (DEFLATE token stage)"},
     "expand": "rle2_expand_kernel (+ rle1 / byte expand: RLE expansion into the Arrow value buffers)",
+    "walk_short": "rle_walk_short_kernel (run boundaries of short-run streams: every byte position parsed, pointer doubling)",
+    "dict_emit": "dict_emit_kernel (dictionary keys -> Utf8 offsets + value bytes)",
 }
-PMC_NAMES = {"seq": "zstd_seq_quads_kernel", "exec": "lz_exec_wave_kernel", "stage1": "zstd_entropy_kernel", "expand": "rle2_expand_kernel"}
+PMC_NAMES = {"seq": "zstd_seq_quads_kernel", "exec": "lz_exec_wave_kernel", "stage1": "zstd_entropy_kernel", "expand": "rle2_expand_kernel",
+             "walk_short": "rle_walk_short_kernel", "dict_emit": "dict_emit_kernel"}
 
 
 def pmc_traffic(workload, comp, kernel_key, algo_bytes_per_launch):
@@ -470,7 +473,7 @@ def roofline_of(lane_acc, comp, workload, step_algo_bytes):
     `achieved` = (sum over the lanes' launches of the algorithmic bytes THAT launch works for: the lane's staged stream bytes in +
     its Arrow bytes out) / (sum of those launches' durations) = algorithmic bytes per launch / average launch duration."""
     best = None
-    for key in ("seq", "exec", "stage1", "expand"):
+    for key in ("seq", "exec", "stage1", "expand", "walk_short", "dict_emit"):
         if key == "stage1" and any(a["seq"] > 0 for a in lane_acc.values()):
             continue  # (table scale: the first stage is the table kernel + the sequences kernel, priced as "seq")
         ls = [a for a in lane_acc.values() if a[key] > 0 and a["steps"]]
@@ -504,7 +507,8 @@ def lanes_of(lane_acc):
         out.append({"lane": l, "stream_bytes": a["stream_bytes"] // n, "arrow_bytes": a["arrow_bytes"] // n, "host_ms_before_first_launch": round(a["start_ms"] / n, 3),
                     "device_ms": round(a["total_ms"] / n, 3), "zstd_tables_ms": round(a["tables"] / n, 3), "zstd_seq_quads_kernel_ms": round(a["seq"] / n, 3),
                     "stage1_ms": round(a["stage1"] / n, 3), "exec_kernel_ms": round(a["exec"] / n, 3), "walk_ms": round(a["walk"] / n, 3),
-                    "expand_ms": round(a["expand"] / n, 3), "finish_ms": round(a["finish"] / n, 3)})
+                    "expand_ms": round(a["expand"] / n, 3), "finish_ms": round(a["finish"] / n, 3),
+                    "rle_walk_short_kernel_ms": round(a["walk_short"] / n, 3), "dict_emit_kernel_ms": round(a["dict_emit"] / n, 3)})
     return out
 
 
@@ -619,7 +623,7 @@ def main():
                 phase[k] += v
             for ls in ctx.lane_stats():
                 a = lane_acc.setdefault(ls["lane"], {"steps": 0, "stream_bytes": 0, "arrow_bytes": 0, "start_ms": 0.0, "total_ms": 0.0, "seq": 0.0, "exec": 0.0,
-                                                     "stage1": 0.0, "tables": 0.0, "expand": 0.0, "walk": 0.0, "finish": 0.0})
+                                                     "stage1": 0.0, "tables": 0.0, "expand": 0.0, "walk": 0.0, "finish": 0.0, "walk_short": 0.0, "dict_emit": 0.0})
                 a["steps"] += 1
                 a["stream_bytes"] += ls["stream_bytes"]
                 a["arrow_bytes"] += ls["arrow_bytes"]
@@ -632,6 +636,8 @@ def main():
                 a["expand"] += ls["phase_ms"]["expand"]
                 a["walk"] += ls["phase_ms"]["walk"]
                 a["finish"] += ls["phase_ms"]["finish"]
+                a["walk_short"] += ls["walk_short_kernel_ms"]
+                a["dict_emit"] += ls["dict_emit_kernel_ms"]
     torch.cuda.synchronize()
     my_dt = time.perf_counter() - t0
     barrier()

@@ -422,6 +422,7 @@ int orcgpu_last_phase_ms(const orcgpu_ctx* ctx, float* ms, uint32_t n);
  *   seq_kernel_ms  Zstandard at table scale: zstd_seq_quads_kernel alone (an event in front of it and one behind it, in front of
  *                  the wait for the literals kernel that runs beside it); 0 when the call had no such launch
  *   exec_kernel_ms the LZ77 execution kernel(s) of the lane (lz_exec_wave_kernel / lz_exec_kernel / lz_exec_tokens_kernel)
+ *   walk_short_kernel_ms, dict_emit_kernel_ms   rle_walk_short_kernel / dict_emit_kernel alone (events around the launch; 0: none)
  * Returns ORCGPU_INVALID_ARGUMENT for a lane the last call did not run. */
 typedef struct orcgpu_lane_stats {
   uint32_t lane, n_lanes;
@@ -429,6 +430,7 @@ typedef struct orcgpu_lane_stats {
   float start_ms, total_ms;
   float phase_ms[ORCGPU_N_PHASES];
   float seq_kernel_ms, exec_kernel_ms;
+  float walk_short_kernel_ms, dict_emit_kernel_ms;
 } orcgpu_lane_stats;
 int orcgpu_last_lane_stats(const orcgpu_ctx* ctx, uint32_t lane, orcgpu_lane_stats* out);
 

@@ -60,7 +60,7 @@ class StripeDesc(C.Structure):
 class LaneStats(C.Structure):
     _fields_ = [("lane", C.c_uint32), ("n_lanes", C.c_uint32), ("stream_bytes", C.c_uint64), ("arrow_bytes", C.c_uint64),
                 ("start_ms", C.c_float), ("total_ms", C.c_float), ("phase_ms", C.c_float * 7), ("seq_kernel_ms", C.c_float),
-                ("exec_kernel_ms", C.c_float)]
+                ("exec_kernel_ms", C.c_float), ("walk_short_kernel_ms", C.c_float), ("dict_emit_kernel_ms", C.c_float)]
 
 
 class RowSelector(C.Structure):
@@ -301,7 +301,8 @@ class Context:
             out.append({"lane": st.lane, "n_lanes": st.n_lanes, "stream_bytes": int(st.stream_bytes), "arrow_bytes": int(st.arrow_bytes),
                         "start_ms": float(st.start_ms), "total_ms": float(st.total_ms),
                         "phase_ms": dict(zip(self.PHASES + ("decompress_stage1", "decompress_tables"), [float(x) for x in st.phase_ms])),
-                        "seq_kernel_ms": float(st.seq_kernel_ms), "exec_kernel_ms": float(st.exec_kernel_ms)})
+                        "seq_kernel_ms": float(st.seq_kernel_ms), "exec_kernel_ms": float(st.exec_kernel_ms),
+                        "walk_short_kernel_ms": float(st.walk_short_kernel_ms), "dict_emit_kernel_ms": float(st.dict_emit_kernel_ms)})
             k += 1
             if k >= st.n_lanes:
                 break

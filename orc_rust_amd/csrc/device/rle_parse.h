@@ -59,6 +59,28 @@ __device__ __forceinline__ T* glob(T* p) {  // typed as_global()
   return (T*)as_global((void*)const_cast<typename std::remove_const<T>::type*>(p));
 }
 
+// n (at most 8) bytes of w into LDS at q, any alignment: one to four stores instead of a store per byte (a lane's loop over its
+// bytes runs as long as the longest of the wavefront's 64)
+__device__ __forceinline__ void lds_put8(uint8_t* q, uint64_t w, uint32_t n) {
+  if (n >= 8) {
+    __builtin_memcpy(q, &w, 8);
+    return;
+  }
+  if (n & 4u) {
+    const uint32_t x = (uint32_t)w;
+    __builtin_memcpy(q, &x, 4);
+    q += 4;
+    w >>= 32;
+  }
+  if (n & 2u) {
+    const uint16_t x = (uint16_t)w;
+    __builtin_memcpy(q, &x, 2);
+    q += 2;
+    w >>= 16;
+  }
+  if (n & 1u) *q = (uint8_t)w;
+}
+
 __device__ __forceinline__ uint64_t ld_u64(const uint8_t* p) {
   uint64_t v;
   __builtin_memcpy(&v, p, 8);

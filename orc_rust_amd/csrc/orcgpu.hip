@@ -246,6 +246,8 @@ struct orcgpu_ctx {
   size_t fin_pinned_cap = 0;
   hipEvent_t ev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk, after the decompressors' first stage, in front of the Zstandard sequences kernel (one lane per block), behind it
   uint32_t n_cus = 0;
+  hipEvent_t kev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // around rle_walk_short_kernel [0] and dict_emit_kernel [1] (orcgpu_last_lane_stats)
+  bool kev_used[2] = {false, false};
   hipStream_t aux_stream = nullptr;   // the Zstandard execution kernel runs here, beside the entropy kernel on `stream`
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
   float last_total_ms = 0, last_expand_ms = 0;
@@ -730,6 +732,12 @@ orcgpu_ctx* orcgpu_open(int device, const orcgpu_opts* opts) {
       delete c;
       return nullptr;
     }
+  for (auto& pr : c->kev)
+    for (auto& e : pr)
+      if (hipEventCreate(&e) != hipSuccess) {
+        delete c;
+        return nullptr;
+      }
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = (uint32_t)prop.multiProcessorCount;
@@ -774,6 +782,9 @@ void orcgpu_close(orcgpu_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : c->aux_ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& pr : c->kev)
+    for (auto& e : pr)
+      if (e) (void)hipEventDestroy(e);
   if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
