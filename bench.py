@@ -546,8 +546,14 @@ def main():
     # this process initialises the GPU.
     stripes, comp, label, shard_desc, plan = build_workload(args, rank, world)
     cpu = None
-    if rank == 0 and not args.no_cpu and world == 1 and stripes:  # timed on rank 0 at N=1 only
+    if rank == 0 and not args.no_cpu and stripes:
+        # rank 0 only, on ITS share of the workload (N > 1: the other ranks wait for it at the rendezvous, their cores are idle)
         cpu = cpu_baseline(stripes, comp)
+        if world > 1:
+            cpu["sample"] += "; rank 0's share of the %d-rank job" % world
+    if world > 1:
+        # one process per GPU on one host: every rank's staging helpers get the rank's share of the usable cores
+        os.environ.setdefault("ORCGPU_STAGE_THREADS", str(max(0, min(6, host_workers(world) - 1))))
     import torch
     dist = None
     # BENCH_BACKEND=gloo is a dry-run aid for boxes with fewer GPUs than ranks (ranks then share devices and

@@ -41,7 +41,8 @@ enum {
   ORCGPU_BUILD_DECODER = 9,     /* Build{Zstd,Snappy,Lz4}Decoder / inflate failure          */
   ORCGPU_UNEXPECTED = 10,       /* Unexpected { msg }                                       */
   ORCGPU_HIP_ERROR = 100,       /* HIP runtime failure (no device, out of memory, ...)      */
-  ORCGPU_INVALID_ARGUMENT = 101
+  ORCGPU_INVALID_ARGUMENT = 101,
+  ORCGPU_END_OF_FILE = 110      /* not an error: orcgpu_reader_next_batch has handed out every batch (Iterator::next -> None) */
 };
 
 /* proto CompressionKind (format/orc_proto.proto:383-390) */
@@ -377,7 +378,7 @@ uint64_t orcgpu_reader_total_rows(const orcgpu_reader* r);                      
 uint32_t orcgpu_reader_stripe_count(const orcgpu_reader* r);
 uint32_t orcgpu_reader_column_count(orcgpu_reader* r);                                               /* projected flat columns */
 const char* orcgpu_reader_column_name(orcgpu_reader* r, uint32_t i);
-/* ArrowReader::next: 0 = one RecordBatch exported (struct array, host memory), 1 = end of file,
+/* ArrowReader::next: 0 = one RecordBatch exported (struct array, host memory), ORCGPU_END_OF_FILE = no more batches,
  * anything else = the OrcError status of the failing batch (the iterator then ends). */
 int orcgpu_reader_next_batch(orcgpu_reader* r, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 

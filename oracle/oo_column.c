@@ -315,19 +315,41 @@ static int decode_dense(oo_column* c, uint8_t* dense, size_t k) {
   }
 }
 
-/* PresentDecoder::next_buffer + derive_present_vec: returns null_count, fills c->validity (LSB-first).
- * `bools` receives one byte per row. */
-static int next_present(oo_column* c, size_t n, uint8_t** bools_out, uint64_t* null_count) {
+/* PresentDecoder::next_buffer + derive_present_vec (array_decoder/mod.rs:199-252): returns null_count, fills c->validity
+ * (LSB-first).  `bools` receives one byte per row.  parent: the Struct / Union arm above the column says which of the n rows
+ * exist at all (one byte per row; NULL: no parent, or a parent without nulls) --
+ *   (own stream, parent)     the stream holds one bit per row the PARENT has: read that many, deal them out (merge_parent_present)
+ *   (own stream, no parent)  n bits
+ *   (no stream, parent)      the parent's
+ *   (neither)                none
+ * and in every case: a buffer without nulls is dropped, and an ERROR is dropped too (`_ => None`, mod.rs:247-251): the batch is
+ * then decoded as if every row were present. */
+static int next_present(oo_column* c, size_t n, const uint8_t* parent, uint8_t** bools_out, uint64_t* null_count) {
   *bools_out = NULL;
   *null_count = 0;
-  if (!c->present) return OO_OK;
+  if (!c->present && !parent) return OO_OK;
   uint8_t* bools = (uint8_t*)malloc(n + 1);
-  int st = oo_bool_decode(c->present, bools, n);
-  if (st) {
-    /* derive_present_vec maps Err to None (mod.rs:247-251: `_ => None`): the error is swallowed
-     * and the batch is decoded as if there were no PRESENT stream. */
-    free(bools);
-    return OO_OK;
+  if (c->present && parent) {
+    size_t have = 0;
+    for (size_t i = 0; i < n; i++) have += parent[i] != 0;
+    uint8_t* own = (uint8_t*)malloc(have + 1);
+    int st = oo_bool_decode(c->present, own, have);
+    if (st) {
+      free(own);
+      free(bools);
+      return OO_OK;
+    }
+    size_t j = 0;
+    for (size_t i = 0; i < n; i++) bools[i] = parent[i] ? own[j++] : 0;
+    free(own);
+  } else if (c->present) {
+    int st = oo_bool_decode(c->present, bools, n);
+    if (st) {
+      free(bools);
+      return OO_OK;
+    }
+  } else {
+    memcpy(bools, parent, n);
   }
   uint64_t nulls = 0;
   for (size_t i = 0; i < n; i++) nulls += !bools[i];
@@ -344,14 +366,16 @@ static int next_present(oo_column* c, size_t n, uint8_t** bools_out, uint64_t* n
   return OO_OK;
 }
 
-int oo_column_next_batch(oo_column* c, uint64_t batch_size, oo_batch* out) {
+int oo_column_next_batch(oo_column* c, uint64_t batch_size, oo_batch* out) { return oo_column_next_batch_under(c, batch_size, NULL, out); }
+
+int oo_column_next_batch_under(oo_column* c, uint64_t batch_size, const uint8_t* parent_present, oo_batch* out) {
   memset(out, 0, sizeof(*out));
   size_t n = (size_t)batch_size;
   out->length = n;
   if (c->dict_status) return out->status = c->dict_status;
   uint8_t* bools = NULL;
   uint64_t nulls = 0;
-  int st = next_present(c, n, &bools, &nulls);
+  int st = next_present(c, n, parent_present, &bools, &nulls);
   if (st) return out->status = st;
   size_t k = n - (size_t)nulls;
   out->null_count = nulls;

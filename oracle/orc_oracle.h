@@ -138,6 +138,9 @@ typedef struct {
 typedef struct oo_column oo_column;
 oo_column* oo_column_new(const oo_column_desc* d, int* status);
 int oo_column_next_batch(oo_column* c, uint64_t batch_size, oo_batch* out);
+/* ... below a Struct / an arm of a Union (next_batch(batch_size, parent_present), array_decoder/mod.rs:61-85): parent_present holds
+ * one byte per row (0: the parent is null there), or is NULL (no parent / a parent without nulls) */
+int oo_column_next_batch_under(oo_column* c, uint64_t batch_size, const uint8_t* parent_present, oo_batch* out);
 
 /* TimestampOffsetArrayDecoder::next_batch (array_decoder/timestamp.rs:236-291): re-labels n decoded TIMESTAMP values of a
  * batch from the writer's zone to UTC.  The zone is a table of UTC instants `at` (ascending, seconds) from which offset

@@ -137,7 +137,7 @@ class ArrowReader:
         a = (C.c_uint8 * 80)()
         s = (C.c_uint8 * 72)()
         rc = self._ctx.L.orcgpu_reader_next_batch(self._h, C.addressof(a), C.addressof(s))
-        if rc == 1:
+        if rc == 110:  # ORCGPU_END_OF_FILE
             raise StopIteration
         self._ctx._check(rc)
         return pa.RecordBatch._import_from_c(C.addressof(a), C.addressof(s))

@@ -161,7 +161,11 @@ struct CopyPool {
   size_t next = 0, pending = 0;
   bool stop = false;
   CopyPool() {
-    for (int i = 0; i < kCopyThreads; i++) threads.emplace_back([this] { run(); });
+    // ORCGPU_STAGE_THREADS: helper threads of a context's staging copies (kCopyThreads by default; 0: the caller alone) -- eight
+    // processes on one host, one per GPU, share its cores: bench.py gives every rank its share
+    int n = kCopyThreads;
+    if (const char* e = getenv("ORCGPU_STAGE_THREADS")) n = std::max(0, std::min(64, atoi(e)));
+    for (int i = 0; i < n; i++) threads.emplace_back([this] { run(); });
   }
   ~CopyPool() {
     {

@@ -37,7 +37,7 @@ for bs in (8192, 65536):
             while True:
                 a, s = ArrowArray(), ArrowSchema()
                 rc = L.orcgpu_reader_next_batch(h, C.byref(a), C.byref(s))
-                if rc == 1: break
+                if rc == 110: break  # ORCGPU_END_OF_FILE
                 assert rc == 0, rc
                 n += a.length; nb += 1
                 a.release(C.addressof(a)); s.release(C.addressof(s))

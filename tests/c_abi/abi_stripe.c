@@ -184,7 +184,7 @@ int main(int argc, char** argv) {
         struct ArrowArray a;
         struct ArrowSchema s;
         rc = orcgpu_reader_next_batch(rd, &a, &s);
-        if (rc == 1) break;
+        if (rc == ORCGPU_END_OF_FILE) break;
         CHECK(rc == ORCGPU_OK);
         if (rc) break;
         CHECK(a.n_children == 2 && a.length <= 2);

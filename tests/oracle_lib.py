@@ -81,6 +81,7 @@ def lib():
         L.oo_column_new.restype = C.c_void_p
         L.oo_column_new.argtypes = [C.POINTER(ColumnDesc), C.POINTER(C.c_int)]
         L.oo_column_next_batch.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Batch)]
+        L.oo_column_next_batch_under.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(Batch)]
         L.oo_column_free.argtypes = [C.c_void_p]
         L.oo_timestamps_to_utc.restype = C.c_uint64
         L.oo_timestamps_to_utc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p]
@@ -233,9 +234,15 @@ class Column:
         self.h = L.oo_column_new(C.byref(d), C.byref(st))
         self.status = st.value
 
-    def next_batch(self, n):
+    def next_batch(self, n, parent_present=None):
+        """parent_present: one byte per row (numpy uint8 / bool; 0: the Struct or Union arm above is null there), None: no parent."""
         b = Batch()
-        lib().oo_column_next_batch(self.h, n, C.byref(b))
+        if parent_present is None:
+            lib().oo_column_next_batch(self.h, n, C.byref(b))
+        else:
+            pp = np.ascontiguousarray(parent_present, dtype=np.uint8)
+            assert pp.size == n
+            lib().oo_column_next_batch_under(self.h, n, pp.ctypes.data, C.byref(b))
         res = {"status": b.status, "length": b.length, "null_count": b.null_count, "validity": None, "values": None, "offsets": None}
         if b.status:
             return res

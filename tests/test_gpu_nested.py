@@ -317,3 +317,125 @@ def test_unions_written_by_the_orc_cpp_writer(tmp_path, compression):
     sel = [(1234, True), (500, False), (n - 1734, True)]
     got = table_of(read_all(path, names=["u"], batch_size=8192, selection=sel))
     assert got.column("u").to_pylist() == want.column("u").slice(1234, 500).to_pylist()
+
+
+# ---- against the nested CPU oracle (tests/oracle_nested.py: the reference's composite decoders restated), batch by batch ------
+def _oracle_batches(path, name, batch_size):
+    import oracle_nested as N
+    import orcfile
+    f = orcfile.OrcFile(path)
+    cid = dict((n, c) for n, c, _ in f.root_columns())[name]
+    return N.read_column(f, cid, batch_size)
+
+
+@pytest.mark.parametrize("name", ["nested_struct", "nested_array", "nested_array_float", "nested_array_struct", "nested_map", "nested_map_struct"])
+def test_the_references_nested_files_batch_by_batch_against_the_oracle(name):
+    path = A.data_path(name + ".orc")
+    for bs in (8192, 2):
+        batches = read_all(path, batch_size=bs)
+        for ci, col in enumerate(batches[0].schema.names):
+            want = _oracle_batches(path, col, bs)
+            assert len(want) == len(batches), (name, col, bs)
+            for b, (g, w) in enumerate(zip(batches, want)):
+                assert g.column(ci).to_pylist() == w.to_pylist(), (name, col, bs, b)
+
+
+def test_written_nested_tables_batch_by_batch_against_the_oracle(tmp_path):
+    rng = np.random.default_rng(9)
+    n = 40_000
+
+    def maybe(v, p=0.1):
+        return None if rng.random() < p else v
+
+    rows = []
+    for i in range(n):
+        inner = maybe({"a": maybe(int(rng.integers(-50, 50))), "s": maybe("x" * int(rng.integers(0, 4)))})
+        rows.append({"st": maybe({"in": inner, "l": maybe([maybe(int(rng.integers(0, 9))) for _ in range(int(rng.integers(0, 4)))]), "k": maybe(i)}),
+                     "m": maybe([(str(int(k)), maybe(float(k))) for k in rng.integers(0, 99, int(rng.integers(0, 3)))])})
+    typ = pa.struct([("st", pa.struct([("in", pa.struct([("a", pa.int64()), ("s", pa.string())])), ("l", pa.list_(pa.int32())), ("k", pa.int64())])),
+                     ("m", pa.map_(pa.string(), pa.float64()))])
+    arr = pa.array(rows, type=typ)
+    path = str(tmp_path / "n.orc")
+    orc.write_table(pa.table({"st": arr.field("st"), "m": arr.field("m")}), path, compression="zstd", stripe_size=1 << 16)
+    for bs in (8192, 1000):
+        batches = read_all(path, batch_size=bs)
+        for ci, col in enumerate(("st", "m")):
+            want = _oracle_batches(path, col, bs)
+            assert len(want) == len(batches)
+            for b, (g, w) in enumerate(zip(batches, want)):
+                assert g.column(ci).to_pylist() == w.to_pylist(), (col, bs, b)
+
+
+def _patched_file(tmp_path, src, edits):
+    """the file with some streams' bytes replaced by bytes of the same length (uncompressed files: a stream lies where the stripe
+    footer says)"""
+    import orcfile
+    f = orcfile.OrcFile(src)
+    assert f.compression_name == "none"
+    buf = bytearray(f.buf)
+    for s in f.stripes:
+        off = s.offset
+        for kind, col, length in s.stream_list:
+            if (col, kind) in edits:
+                new = edits[(col, kind)](bytes(buf[off:off + length]))
+                assert len(new) == length
+                buf[off:off + length] = new
+            off += length
+    p = str(tmp_path / "patched.orc")
+    open(p, "wb").write(bytes(buf))
+    return p
+
+
+def test_the_two_documented_differences_on_corrupt_nested_input(tmp_path):
+    """DESIGN 2 names two places where corrupt NESTED input is handled differently from the reference; the nested oracle says what
+    the reference does, the test pins what this path does (and that valid input around it is untouched).
+    (1) A Struct FIELD whose PRESENT stream fails: the reference drops the field's validity for the batch (derive_present_vec,
+        mod.rs:247-251) and decodes n values; here the bits the stream did not deliver read as present.
+    (2) A failure among the ELEMENTS of a List: the reference fails the batch whose elements run dry; here the elements of a
+        stripe are one batch: the stripe fails in its first batch."""
+    import oracle_nested as N
+    import orcfile
+    rng = np.random.default_rng(2)
+    n = 20_000
+    vals = pa.array(rng.integers(0, 1000, n), mask=rng.random(n) < 0.3)
+    st = pa.StructArray.from_arrays([vals], names=["v"], mask=pa.array(rng.random(n) < 0.2))
+    lst = pa.array([[int(x) for x in rng.integers(0, 9, int(rng.integers(0, 4)))] for _ in range(n)], type=pa.list_(pa.int64()))
+    src = str(tmp_path / "src.orc")
+    orc.write_table(pa.table({"st": st, "l": lst}), src, compression="uncompressed", stripe_size=1 << 26)
+    f = orcfile.OrcFile(src)
+    assert len(f.stripes) == 1
+    root = dict((nm, c) for nm, c, _ in f.root_columns())
+    field = f.types[root["st"]].subtypes[0]
+    elem = f.types[root["l"]].subtypes[0]
+    # (1) the field's PRESENT stream cut short by a byte-RLE header that promises more bytes than the stream has
+    p1 = _patched_file(tmp_path, src, {(field, N.PRESENT): lambda b: b[:len(b) // 2] + bytes([0x81]) + b[len(b) // 2 + 1:][: len(b) - len(b) // 2 - 1]})
+    want = _oracle_batches(p1, "st", 8192)  # (the oracle does not fail: the error is swallowed)
+    got = read_all(p1, names=["st"], batch_size=8192)
+    assert len(got) == len(want)
+    g_all = pa.chunked_array([b.column(0) for b in got]).combine_chunks()
+    w_all = pa.chunked_array(want).combine_chunks()
+    assert g_all.is_valid().to_pylist() == w_all.is_valid().to_pylist()  # the Struct's own validity: the same
+    same = [b for b, (g, w) in enumerate(zip(got, want)) if g.column(0).to_pylist() == w.to_pylist()]
+    assert same and same[0] == 0  # every batch in front of the damage is the oracle's, bit for bit
+    # (2) the elements' DATA stream cut short: the reference fails at the batch that runs dry, this path in the stripe's first batch
+    # (600 bytes of 0x7f: longer than a run of these one-byte values, so a run HEADER lies in them -- DIRECT, 64 bits wide, 384 values:
+    # the stream runs dry)
+    p2 = _patched_file(tmp_path, src, {(elem, N.DATA): lambda b: b[:len(b) - 600] + bytes([0x7f] * 600)})
+    ok_batches = 0
+    try:
+        f2 = orcfile.OrcFile(p2)
+        node = N.build(f2, f2.stripes[0], root["l"])
+        left = n
+        while left > 0:
+            node.next_batch(min(8192, left), None)
+            left -= 8192
+            ok_batches += 1
+        oracle_fails = None
+    except N.OracleError as e:
+        oracle_fails = e.status
+    assert oracle_fails == 1 and ok_batches == 2  # IoError, in the stripe's LAST batch: two batches come out of the reference
+    got = []
+    with pytest.raises(capi.OrcGpuError) as ei:
+        for b in ArrowReaderBuilder.try_new(p2, ctx()).with_projection(["l"]).with_batch_size(8192).build():
+            got.append(b)
+    assert ei.value.code == oracle_fails and len(got) == 0  # the same error kind; in the stripe's FIRST batch (documented)

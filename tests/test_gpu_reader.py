@@ -3,7 +3,9 @@ tests/basic/main.rs and tests/integration/main.rs do (open -> iterate RecordBatc
 the expected table), plus the builder knobs (batch size, projection, byte-range stripe filter)."""
 import os
 
+import numpy as np
 import pyarrow as pa
+import pyarrow.orc as orc
 import pytest
 
 import arrow_util as A
@@ -218,3 +220,40 @@ def test_errors_arrive_in_order_when_reading_ahead():
         with pytest.raises(capi.OrcGpuError) as e:
             list(r)
         assert e.value.code == 4
+
+
+def test_an_io_error_ends_the_iterator_with_that_error(tmp_path):
+    """The failing batch of a stripe may fail with ANY OrcError -- IoError is status 1 --: the end of the file has a code of its own
+    (ORCGPU_END_OF_FILE), so a stream that runs dry is reported, not taken for the end (arrow_reader.rs:333-346: the iterator
+    yields the error, then ends).  Batches in front of the failing one are the file's."""
+    import orcfile
+    n = 30_000
+    t = pa.table({"a": pa.array(np.arange(n, dtype=np.int64) * 977 % 100003), "b": pa.array(np.arange(n, dtype=np.int32))})
+    src = str(tmp_path / "src.orc")
+    orc.write_table(t, src, compression="uncompressed", stripe_size=1 << 26)
+    f = orcfile.OrcFile(src)
+    cid = dict((nm, c) for nm, c, _ in f.root_columns())["a"]
+    buf = bytearray(f.buf)
+    s = f.stripes[0]
+    off = s.offset
+    for kind, col, length in s.stream_list:
+        if (col, kind) == (cid, 1):
+            buf[off + length - 2000:off + length] = bytes([0x7f]) * 2000  # a DIRECT header that promises more than the stream holds
+        off += length
+    bad = str(tmp_path / "bad.orc")
+    open(bad, "wb").write(bytes(buf))
+    oc = orcfile.OrcFile(bad).oracle_column(orcfile.OrcFile(bad).stripes[0], cid)
+    ok = 0
+    while True:
+        b = oc.next_batch(8192)
+        if b["status"]:
+            break
+        ok += 1
+    assert b["status"] == 1 and 0 < ok < 4
+    for prefetch in (0, 2):
+        got = []
+        with pytest.raises(capi.OrcGpuError) as ei:
+            for rb in ArrowReaderBuilder.try_new(bad, ctx()).with_batch_size(8192).with_prefetch(prefetch).build():
+                got.append(rb)
+        assert ei.value.code == 1 and len(got) == ok, (prefetch, len(got), ok)
+        assert pa.Table.from_batches(got).column("a").to_pylist() == t.column("a").to_pylist()[:ok * 8192]
