@@ -1,0 +1,78 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): everything the r05_* files of profiles/ are built from.  Output under gpurun_out/r05c/.
+#   gpurun --timeout 3000 -- 'bash profiles/collect_r05.sh'        then here:  python profiles/summarise_r05.py
+# Every profiler pass runs under its own `timeout` (a pass that hangs must not take the rest with it) and is checked by the
+# summariser: a missing pass is an error there, never a zero.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r05c
+rm -rf $O; mkdir -p $O
+cd $R
+# 1. the driver's line: default workload (lineitem, one GPU's share of SF100 = SF 12.5, Zstandard), CPU baseline included
+timeout 900 python bench.py > $O/bench_line.json 2> $O/bench_line.err
+# 2. where GB/s saturates: scale factors 1 .. 50 of the same table
+for sf in 1 2 4 8 12.5 25 50; do
+  timeout 900 python bench.py --sf $sf --steps 5 --warmup 2 --no-cpu --no-e2e 2> $O/sf_$sf.err | tail -1 > $O/sf_$sf.json
+done
+# 3. one bench line + one kernel table per workload / codec
+cd /tmp && export TMPDIR=/tmp
+run() {  # tag, bench args...
+  tag=$1; shift
+  ( cd $R && timeout 600 python bench.py "$@" --steps 10 --warmup 3 --no-cpu 2> $O/$tag.err | tail -1 > $O/line_$tag.json )
+  ( cd $R && timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw_$tag -- python3 bench.py "$@" --steps 5 --warmup 2 --no-cpu --skip-check --no-e2e > /dev/null 2> $O/prof_$tag.err )
+  f=$(find $O/raw_$tag -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" $O/kernel_stats_$tag.csv
+  rm -rf $O/raw_$tag
+}
+run lineitem_zstd --workload lineitem --compression zstd
+for c in snappy lz4 zlib none; do run lineitem_$c --workload lineitem --compression $c --sf 4; done
+run c2 --workload c2
+run c2_adv --workload c2-adv --rows 24000000
+run c2_adv_noindex --workload c2-adv --rows 24000000 --no-row-index
+run c2_rowgroup --workload c2-rowgroup
+run c2_rowgroup_noindex --workload c2-rowgroup --no-row-index
+for c in none snappy zstd lz4 zlib; do run c3_$c --workload c3 --compression $c; done
+for c in none snappy; do run c3_${c}_index --workload c3 --compression $c --row-index; done
+run c5_lz4 --workload c5 --compression lz4
+# 3b. the timeline of one headline step (kernel, queue, start, end): what runs beside what
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/raw_trace -- python3 $R/bench.py --steps 4 --warmup 3 --no-cpu --skip-check --no-e2e > /dev/null 2> $O/prof_trace.err )
+python3 profiles/timeline.py $O/raw_trace 30 > $O/timeline_lineitem_zstd.txt 2>&1
+( cd /tmp && ORCGPU_LANES=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/raw_trace1 -- python3 $R/bench.py --steps 4 --warmup 3 --no-cpu --skip-check --no-e2e > /dev/null 2> $O/prof_trace1.err )
+python3 profiles/timeline.py $O/raw_trace1 30 > $O/timeline_lineitem_zstd_one_lane.txt 2>&1
+rm -rf $O/raw_trace1
+rm -rf $O/raw_trace
+# 3c. what a row selection / a predicate costs with row-group pruning; the reader's own rate
+( cd $R && timeout 600 python profiles/select_cost.py 24000000 > $O/select_cost.json 2> $O/select_cost.err )
+( cd $R && timeout 600 python profiles/reader_rate.py 24000000 > $O/reader_rate.json 2> $O/reader_rate.err )
+# 4. HBM traffic of the headline (SF 4: the table-scale kernels, 11 stripes) and of C3 / C2: FETCH_SIZE and WRITE_SIZE in passes of
+#    their own (no trace domain beside --kernel-trace), each bounded
+pmc() {  # tag, counter, bench args...
+  tag=$1; cnt=$2; shift; shift
+  ( cd $R && timeout 600 rocprofv3 --kernel-trace --pmc $cnt --output-format csv -d $O/raw_pmc -- python3 bench.py "$@" --steps 2 --warmup 1 --no-cpu --skip-check --no-e2e > /dev/null 2> $O/pmc_${tag}_$cnt.err )
+  f=$(find $O/raw_pmc -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && cp "$f" $O/pmc_${tag}_$cnt.csv
+  rm -rf $O/raw_pmc
+}
+for cnt in FETCH_SIZE WRITE_SIZE; do
+  pmc lineitem_zstd_sf12 $cnt --workload lineitem --compression zstd
+  pmc lineitem_zstd $cnt --workload lineitem --compression zstd --sf 4
+  pmc c3_none $cnt --workload c3 --compression none
+  pmc c2 $cnt --workload c2
+done
+( cd $R && timeout 300 python bench.py --workload lineitem --compression zstd --sf 4 --steps 5 --warmup 2 --no-cpu --no-e2e 2> /dev/null | tail -1 > $O/line_lineitem_zstd_sf4.json )
+# run-to-run spread of the headline: five more lines
+for i in 1 2 3 4 5; do ( cd $R && timeout 300 python bench.py --no-cpu --no-e2e --skip-check 2> /dev/null | tail -1 > $O/repeat_$i.json ); done
+# the counter files are large (one row per dispatch): keep per-kernel averages only
+python3 - $O <<'PY'
+import csv, sys, glob, json, collections, os
+O = sys.argv[1]
+out = {}
+for f in sorted(glob.glob(O + '/pmc_*_*.csv')):
+    tag = os.path.basename(f)[4:-4]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+    out[tag] = {k: {"launches": len(v), "avg": sum(v) / len(v), "sum": sum(v)} for k, v in acc.items()}
+    os.remove(f)
+json.dump(out, open(O + '/pmc_per_kernel.json', 'w'), indent=1)
+PY
+ls -la $O | head -90
