@@ -30,7 +30,7 @@ struct RleJob {
   uint32_t stat_repaired;  // repair kernel: blocks rewritten (diagnostics)
   uint32_t skip;           // a stream entered at a row group (orcgpu_stream::skip_values): values of its first run that belong to
                            // the rows before; they are decoded in front of the column's values (the consumers start behind them)
-  uint32_t pad;
+  uint32_t bad_left;       // inconsistent blocks the last mending pass left (rle_walk_kernel mode 5): RLE_EXACT_MIN or more: the exact parallel walk
   // verified run starts (orcgpu_stream::entries): this job's slice of the call's RleHint table; hint_bad is set by
   // rle_hint_kernel when the entries do not lie on one run chain (they are then ignored)
   uint32_t hint0, n_hints, hint_bad, hint_skip;

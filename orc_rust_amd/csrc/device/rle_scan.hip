@@ -26,6 +26,7 @@
 #include "rle_parse.h"
 
 #define RLE_MEND_MIN 64u  // inconsistent blocks a stream must have for the parallel mending passes (rle_mend_kernel)
+#define RLE_EXACT_MIN 32u  // inconsistent blocks the mending passes may leave before the stream takes the exact parallel walk (rle_exact_*)
 
 // Phase timing for development builds (-DORC_PROF): per-phase sum / max of wavefront wall-clock ticks (10 ns).
 #ifdef ORC_PROF
@@ -381,6 +382,10 @@ __device__ __forceinline__ bool chain_hits(const uint8_t* data, uint64_t len, ui
   return p == target;
 }
 
+__device__ __forceinline__ bool rle_hopeless(const RleJob* j, uint64_t len) {
+  const uint64_t nb = (len + RLE_BLK - 1) / RLE_BLK;
+  return j->stat_bad >= RLE_MEND_MIN && (uint64_t)j->stat_bad * 8 >= nb;
+}
 // mode 0: guess; 1: relaxation round; 2: verify only; 3: strong blocks fill their pass-through blocks.
 // Every wavefront covers 64 consecutive blocks of ONE stream (block ranges are RLE_TILE aligned).
 extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
@@ -585,13 +590,14 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
   }
   // mode 2: verify; mode 5: verify again behind rle_mend_kernel (only the streams it worked on)
   if (mode == 5) {
-    if (j->stat_bad < RLE_MEND_MIN) return;
+    if (j->stat_bad < RLE_MEND_MIN || rle_hopeless(j, len)) return;
     // the bitmap words are written afresh (rle_mend_kernel reads them as a snapshot and leaves them alone)
     const uint32_t want5 = lb == 0 ? 0u : blk.exit_[b - 1];
     const bool bad = want5 != blk.entry[b];
     const unsigned long long m = __ballot(bad);
     blk.badmap[b >> 5] = (uint32_t)(lane < 32 ? m : m >> 32);  // (every lane of the half stores the same word)
     if (bad) atomicMin(&j->first_bad, lb);
+    if (m && lane == 0) atomicAdd(&j->bad_left, (uint32_t)__builtin_popcountll(m));  // what this mending pass left (rle_exact_*)
     return;
   }
   uint32_t want = lb == 0 ? 0u : blk.exit_[b - 1];
@@ -990,6 +996,11 @@ extern "C" __global__ void __launch_bounds__(256) rle_mend_kernel(RleJob* jobs, 
   if (j->stat_bad < RLE_MEND_MIN) return;  // (the whole wavefront: block ranges of a job are tile aligned)
   const uint32_t lb = b - j->block0;
   const uint64_t len = scalars[j->len_idx];
+  if (rle_hopeless(j, len)) {
+    // an eighth of the stream's blocks inconsistent: no regular stream with a few damaged stretches -- the exact walk takes it
+    if (lb == 0) j->bad_left = j->stat_bad;
+    return;
+  }
   if (lb >= j->nblocks || !((uint64_t)lb * RLE_BLK < len || lb == 0)) return;
   const uint32_t b0 = j->block0;
   auto flagged = [&](uint32_t pb) { return ((blk.badmap[(b0 + pb) >> 5] >> ((b0 + pb) & 31)) & 1u) != 0; };
@@ -1045,7 +1056,10 @@ extern "C" __global__ void __launch_bounds__(256) rle_mend_kernel(RleJob* jobs, 
     done++;
   }
   atomicAdd(&j->stat_repaired, done);
-  if (lb == j->first_bad) j->first_bad = 0xffffffffu;  // the verify round behind this kernel finds the first one again (the first inconsistent block of a stream always heads a stretch)
+  if (lb == j->first_bad) {
+    j->first_bad = 0xffffffffu;  // the verify round behind this kernel finds the first one again (the first inconsistent block of a stream always heads a stretch)
+    j->bad_left = 0;             // ... and counts what is left
+  }
 }
 
 extern "C" __global__ void __launch_bounds__(64) rle_repair_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars) {
@@ -1058,6 +1072,172 @@ extern "C" __global__ void __launch_bounds__(64) rle_repair_kernel(RleJob* jobs,
   if (j->codec == CODEC_RLE2) repair_chain<CODEC_RLE2>(j, blk, len, nb, lane);
   else if (j->codec == CODEC_RLE1) repair_chain<CODEC_RLE1>(j, blk, len, nb, lane);
   else repair_chain<CODEC_BYTE>(j, blk, len, nb, lane);
+}
+
+// ---- streams the heuristics cannot settle: the EXACT walk, in parallel ------------------------------------------------------
+// Long runs of ever-changing size (bench.py's c2-adv; a file written without ROW_INDEX positions): no stride to prove, no
+// candidate that verifies, and a chain started at a wrong byte does not meet the true one within a warm-up -- what the mending
+// passes leave used to go to rle_repair_kernel, one dependent memory access per run (23 ms per 24 M rows).  The exact answer
+// without a serial chain: a SPAN of 256 blocks is a function from where a chain enters it to where that chain leaves it, and
+// functions compose.
+//   rle_exact_map_kernel    one workgroup per span: for EVERY entry e in [0, RLE_EXACT_E) -- a run is at most 512 eight-byte
+//                           values, a patch list and a header long: no chain enters a span further in -- the exit of the chain
+//                           from e, all 4608 chains at once, through the all-entries tables of the span's blocks (block_exit_table)
+//   rle_exact_tile_kernel   the maps of a tile's four spans composed (a tile = RLE_TILE blocks never holds two streams)
+//   rle_exact_chain_kernel  one wavefront per stream: the true chain from byte 0 through the tiles' maps (a lookup per tile:
+//                           191 for 100 MB), then -- tiles side by side -- through the spans' maps: every span's true entry
+//   rle_exact_fill_kernel   one workgroup per span: its blocks' entry / exit / value count from the span's entry
+// Streams take part whose last mending pass left RLE_EXACT_MIN or more inconsistent blocks; all four kernels end at once for the
+// others.  The stream's blocks are then exact by construction: rle_repair_kernel has nothing to do (first_bad = none).
+#define RLE_EXACT_E 4608u     // bytes from a span's start within which a chain may enter it (RLE v2: 4 + 512 * 8 + 31 * 8 patch bytes)
+#define RLE_EXACT_SPAN 256u   // blocks per span (RLE_TILE / 4)
+#define RLE_EXACT_WG 512
+__device__ __forceinline__ bool exact_span(const RleJob* jobs, int njobs, const uint64_t* scalars, uint32_t g, uint32_t total_blocks, RleJob*& j,
+                                           uint32_t& lb0, uint64_t& len) {
+  const uint32_t bw = g * RLE_EXACT_SPAN;
+  if (bw >= total_blocks) return false;
+  j = const_cast<RleJob*>(find_job_by_block(jobs, njobs, bw));
+  if (j->bad_left < RLE_EXACT_MIN) return false;
+  lb0 = bw - j->block0;
+  len = scalars[j->len_idx];
+  return lb0 < j->nblocks && (uint64_t)lb0 * RLE_BLK < len;
+}
+template <int CODEC>
+__device__ __forceinline__ void exact_tables(const RleJob* j, uint64_t len, uint32_t lbv, uint32_t (*tab)[RLE_BLK], int* which, uint32_t lane) {
+  const bool live = lbv < j->nblocks && (uint64_t)lbv * RLE_BLK < len;
+  int c = -1;
+  if (live) block_exit_table<CODEC>(as_global(j->data), len, lbv, j->is_signed, j->nbits, tab, lane, c);
+  if (lane == 0) *which = c;
+}
+__device__ __forceinline__ void exact_tables_any(const RleJob* j, uint64_t len, uint32_t lbv, uint32_t (*tab)[RLE_BLK], int* which, uint32_t lane) {
+  if (j->codec == CODEC_RLE2) exact_tables<CODEC_RLE2>(j, len, lbv, tab, which, lane);
+  else if (j->codec == CODEC_RLE1) exact_tables<CODEC_RLE1>(j, len, lbv, tab, which, lane);
+  else exact_tables<CODEC_BYTE>(j, len, lbv, tab, which, lane);
+}
+extern "C" __global__ void __launch_bounds__(RLE_EXACT_WG) rle_exact_map_kernel(RleJob* jobs, int njobs, const uint64_t* scalars, uint32_t total_blocks, uint16_t* fmap) {
+  __shared__ uint32_t tabs[8][2][RLE_BLK];
+  __shared__ int which[8];
+  __shared__ uint32_t cur[RLE_EXACT_E];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t n_spans = (total_blocks + RLE_EXACT_SPAN - 1) / RLE_EXACT_SPAN;
+  for (uint32_t g = blockIdx.x; g < n_spans; g += gridDim.x) {
+    RleJob* j;
+    uint32_t lb0;
+    uint64_t len;
+    if (!exact_span(jobs, njobs, scalars, g, total_blocks, j, lb0, len)) continue;  // (the whole workgroup)
+    __syncthreads();
+    for (uint32_t e = tid; e < RLE_EXACT_E; e += RLE_EXACT_WG) cur[e] = e;
+    for (uint32_t k0 = 0; k0 < RLE_EXACT_SPAN; k0 += 8) {
+      exact_tables_any(j, len, lb0 + k0 + wv, tabs[wv], &which[wv], lane);
+      __syncthreads();
+      for (uint32_t e = tid; e < RLE_EXACT_E; e += RLE_EXACT_WG) {
+        uint32_t p = cur[e];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++)
+          if ((p >> 9) == k0 + q) {
+            const int c = which[q];
+            // (behind the stream's end: the chain is over; its exit is of no interest to anybody)
+            p = c < 0 ? RLE_EXACT_SPAN * RLE_BLK : (k0 + q) * RLE_BLK + (tabs[q][c][p & (RLE_BLK - 1)] & 0xffffu);
+          }
+        cur[e] = p;
+      }
+      __syncthreads();
+    }
+    for (uint32_t e = tid; e < RLE_EXACT_E; e += RLE_EXACT_WG) {
+      const uint32_t p = cur[e];
+      const uint32_t x = p >= RLE_EXACT_SPAN * RLE_BLK ? p - RLE_EXACT_SPAN * RLE_BLK : 0u;
+      fmap[(size_t)g * RLE_EXACT_E + e] = (uint16_t)(x < RLE_EXACT_E ? x : RLE_EXACT_E - 1);
+    }
+  }
+}
+extern "C" __global__ void __launch_bounds__(RLE_EXACT_WG) rle_exact_tile_kernel(RleJob* jobs, int njobs, const uint64_t* scalars, uint32_t total_blocks, const uint16_t* fmap,
+                                                                                 uint16_t* gmap) {
+  const uint32_t n_tiles = total_blocks / RLE_TILE;
+  for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    RleJob* j;
+    uint32_t lb0;
+    uint64_t len;
+    if (!exact_span(jobs, njobs, scalars, t * 4, total_blocks, j, lb0, len)) continue;
+    for (uint32_t e = threadIdx.x; e < RLE_EXACT_E; e += RLE_EXACT_WG) {
+      uint32_t x = e;
+      for (uint32_t s = 0; s < 4; s++) {
+        const uint32_t lbs = lb0 + s * RLE_EXACT_SPAN;
+        if (lbs < j->nblocks && (uint64_t)lbs * RLE_BLK < len) x = fmap[(size_t)(t * 4 + s) * RLE_EXACT_E + x];
+      }
+      gmap[(size_t)t * RLE_EXACT_E + e] = (uint16_t)x;
+    }
+  }
+}
+extern "C" __global__ void __launch_bounds__(64) rle_exact_chain_kernel(RleJob* jobs, int njobs, const uint64_t* scalars, const uint16_t* fmap, const uint16_t* gmap,
+                                                                        uint32_t* tile_entry, uint32_t* span_entry) {
+  RleJob* j = &jobs[blockIdx.x];
+  if (j->bad_left < RLE_EXACT_MIN) return;
+  const uint64_t len = scalars[j->len_idx];
+  uint32_t nb = (uint32_t)((len + RLE_BLK - 1) / RLE_BLK);
+  if (nb > j->nblocks) nb = j->nblocks;
+  const uint32_t t0 = j->block0 / RLE_TILE, nt = (nb + RLE_TILE - 1) / RLE_TILE;
+  const uint32_t lane = threadIdx.x;
+  if (lane == 0) {
+    uint32_t x = 0;  // (a stream starts with a run header)
+    for (uint32_t t = 0; t < nt; t++) {
+      tile_entry[t0 + t] = x;
+      x = gmap[(size_t)(t0 + t) * RLE_EXACT_E + x];
+    }
+    __threadfence();
+  }
+  wave_sync_scan();
+  for (uint32_t t = lane; t < nt; t += 64) {
+    uint32_t x = __hip_atomic_load(&tile_entry[t0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t s = 0; s < 4; s++) {
+      const uint32_t g = (t0 + t) * 4 + s, lbs = (t * 4 + s) * RLE_EXACT_SPAN;
+      span_entry[g] = x;
+      if (lbs < nb) x = fmap[(size_t)g * RLE_EXACT_E + x];
+    }
+  }
+  if (lane == 0) j->first_bad = 0xffffffffu;  // exact from here on: nothing for rle_repair_kernel
+}
+extern "C" __global__ void __launch_bounds__(RLE_EXACT_WG) rle_exact_fill_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars, uint32_t total_blocks,
+                                                                                 const uint32_t* span_entry) {
+  __shared__ uint32_t tabs[8][2][RLE_BLK];
+  __shared__ int which[8];
+  __shared__ uint32_t carry;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t n_spans = (total_blocks + RLE_EXACT_SPAN - 1) / RLE_EXACT_SPAN;
+  for (uint32_t g = blockIdx.x; g < n_spans; g += gridDim.x) {
+    RleJob* j;
+    uint32_t lb0;
+    uint64_t len;
+    if (!exact_span(jobs, njobs, scalars, g, total_blocks, j, lb0, len)) continue;
+    __syncthreads();
+    if (tid == 0) carry = span_entry[g];
+    for (uint32_t k0 = 0; k0 < RLE_EXACT_SPAN; k0 += 8) {
+      exact_tables_any(j, len, lb0 + k0 + wv, tabs[wv], &which[wv], lane);
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t e = carry;  // where the chain stands, relative to the start of block k0
+        for (uint32_t q = 0; q < 8; q++) {
+          const int c = which[q];
+          if (c < 0) break;  // behind the stream's end
+          const uint32_t b = j->block0 + lb0 + k0 + q;
+          uint32_t ex = 0, nv = 0;
+          if (e >= RLE_BLK) {
+            ex = e - RLE_BLK;  // a run reaches over the block
+          } else {
+            const uint32_t v = tabs[q][c][e];
+            const uint32_t to = v & 0xffffu;
+            nv = v >> 16;
+            ex = to > RLE_BLK ? to - RLE_BLK : 0u;
+          }
+          blk.entry[b] = e;
+          blk.exit_[b] = ex;
+          blk.nvals[b] = nv;
+          e = ex;
+        }
+        carry = e;
+      }
+      __syncthreads();
+    }
+  }
 }
 
 // Exclusive scan of nvals inside each RLE_TILE-block tile (one workgroup per tile).
