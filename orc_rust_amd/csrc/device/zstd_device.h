@@ -277,20 +277,6 @@ __device__ __forceinline__ void hb_skip(HBits& h, int nb) {
   }
 }
 
-// A BURST: hb_seek, then up to hb_burst(mb) symbols stepped with hb_step -- no load, no branch; then the next seek.
-// The loop above asked for its next word whenever SOME lane's window had moved: with 64 lanes that is every iteration, and the
-// wait in front of that load's use is a wait for the load the iteration before issued (one in-order counter per wavefront):
-// a memory round trip per symbol (~0.9 us a symbol and wavefront at table scale).  A seek leaves 56..63 bits in the window's top
-// word, 64 in the word below and 64 in `nx`: 120 bits can be consumed before a second word would be needed.
-__device__ __forceinline__ uint32_t hb_burst(int mb) { return 120u / (uint32_t)(mb > 0 ? mb : 1); }
-__device__ __forceinline__ void hb_step(HBits& h, int nb) {
-  h.pos -= nb;
-  const bool move = h.pos < h.wb64;
-  h.hi1 = move ? h.lo << 1 : h.hi1;
-  h.lo = move ? (h.nxs >= 64u ? 0ull : h.nx << h.nxs) : h.lo;
-  h.wb64 -= move ? 64 : 0;
-}
-
 __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const uint8_t* sp, uint32_t sn, uint8_t* out, uint32_t outn, uint32_t k,
                                               uint32_t lps, bool on PROF_PARM) {
   int bad = 0;
@@ -314,7 +300,6 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
   // decodes only until it stands on one of those marks.  Lanes whose start did not change keep what they have.
   int ck0 = -1, ck1 = -1, ck2 = -1, ck3 = -1;
   bool redo = true;
-  const uint32_t burst = hb_burst(mb);
   PROF_MARK(3);
   for (uint32_t round = 0; round < lps; round++) {
     if (work && redo) {
@@ -323,59 +308,51 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
       cnt = 0;
       endpos = start;
       if (start > pn) {
-        h.pos = start;
+        hb_seek(h, start);
         bool met = false;
         if (round == 0) {
           uint32_t limit = 16, jj = 0;
-          while (h.pos > pn && !bad) {
-            hb_seek(h, h.pos);
-            for (uint32_t b = 0; b < burst; b++) {
-              if (h.pos <= pn) break;
-              const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
-              const int nb = (int)(e >> 8);
-              if (nb == 0) {  // not a table zstd builds: no progress possible
-                bad = 1;
-                break;
-              }
-              cnt++;
-              hb_step(h, nb);
-              if (cnt == limit) {
-                if (jj == 0) ck0 = h.pos;
-                else if (jj == 1) ck1 = h.pos;
-                else if (jj == 2) ck2 = h.pos;
-                else if (jj == 3) ck3 = h.pos;
-                jj++;
-                limit <<= 2;
-              }
+          while (h.pos > pn) {
+            const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
+            const int nb = (int)(e >> 8);
+            if (nb == 0) {  // not a table zstd builds: no progress possible
+              bad = 1;
+              break;
+            }
+            cnt++;
+            hb_skip(h, nb);
+            if (cnt == limit) {
+              if (jj == 0) ck0 = h.pos;
+              else if (jj == 1) ck1 = h.pos;
+              else if (jj == 2) ck2 = h.pos;
+              else if (jj == 3) ck3 = h.pos;
+              jj++;
+              limit <<= 2;
             }
           }
         } else {
           // (marks are only trusted in round 1: later rounds -- rare -- decode their segment whole)
           uint32_t jj = round == 1 ? 0u : 4u;
-          while (h.pos > pn && !met && !bad) {
-            hb_seek(h, h.pos);
-            for (uint32_t b = 0; b < burst; b++) {
-              if (h.pos <= pn) break;
-              if (jj < 4) {
-                int ck = jj == 0 ? ck0 : (jj == 1 ? ck1 : (jj == 2 ? ck2 : ck3));
-                while (jj < 4 && h.pos < ck) {  // passed without standing on it (a mark never reached is -1: below everything)
-                  jj++;
-                  ck = jj == 1 ? ck1 : (jj == 2 ? ck2 : ck3);
-                }
-                if (jj < 4 && h.pos == ck) {
-                  met = true;
-                  break;
-                }
+          while (h.pos > pn) {
+            if (jj < 4) {
+              int ck = jj == 0 ? ck0 : (jj == 1 ? ck1 : (jj == 2 ? ck2 : ck3));
+              while (jj < 4 && h.pos < ck) {  // passed without standing on it (a mark never reached is -1: below everything)
+                jj++;
+                ck = jj == 1 ? ck1 : (jj == 2 ? ck2 : ck3);
               }
-              const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
-              const int nb = (int)(e >> 8);
-              if (nb == 0) {
-                bad = 1;
+              if (jj < 4 && h.pos == ck) {
+                met = true;
                 break;
               }
-              cnt++;
-              hb_step(h, nb);
             }
+            const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
+            const int nb = (int)(e >> 8);
+            if (nb == 0) {
+              bad = 1;
+              break;
+            }
+            cnt++;
+            hb_skip(h, nb);
           }
           if (met) {
             cnt += cnt_old - (16u << (2 * jj));  // the old path had 16 * 4^jj symbols above this mark
@@ -406,28 +383,35 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
   const int last_end = __shfl(endpos, glast);
   if (work && (total != outn || last_end != 0)) bad = 1;
   if (work && !bad && start > pn) {
-    // symbols leave eight at a time (one 8-byte store instead of eight scattered single-byte ones: the
-    // stores of a block used to take longer to drain than the decoding itself)
-    uint32_t i = incl - cnt, nacc = 0;
-    uint64_t acc = 0;
-    h.pos = start;
+    // symbols leave SIXTEEN at a time, from the first 16-byte boundary of the lane's part of the output on: a lane's part lies
+    // between its neighbours' -- an 8-byte store at any alignment was written to memory as the 32-byte piece around it (3.9 x the
+    // literals in HBM writes by the counters), a whole aligned 16-byte store is half a piece
+    uint32_t i = incl - cnt;
+    uint64_t acc0 = 0, acc1 = 0;
+    uint32_t nacc = 0;
+    // (bytes up to the boundary one by one)
+    uint32_t head = (uint32_t)((16u - ((uint32_t)(uintptr_t)(out + i) & 15u)) & 15u);
+    hb_seek(h, start);
     while (h.pos > pn) {
-      hb_seek(h, h.pos);
-      for (uint32_t b = 0; b < burst; b++) {
-        if (h.pos <= pn) break;
-        const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
-        const int nb = (int)(e >> 8);
-        acc |= (uint64_t)(e & 0xff) << (8 * nacc);
-        if (++nacc == 8) {
-          __builtin_memcpy(out + i, &acc, 8);
-          i += 8;
+      const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
+      const int nb = (int)(e >> 8);
+      if (head) {
+        out[i++] = (uint8_t)e;
+        head--;
+      } else {
+        if (nacc < 8) acc0 |= (uint64_t)(e & 0xff) << (8 * nacc);
+        else acc1 |= (uint64_t)(e & 0xff) << (8 * (nacc - 8));
+        if (++nacc == 16) {
+          const uint64_t v[2] = {acc0, acc1};
+          __builtin_memcpy(__builtin_assume_aligned(out + i, 16), v, 16);
+          i += 16;
           nacc = 0;
-          acc = 0;
+          acc0 = acc1 = 0;
         }
-        hb_step(h, nb);
       }
+      hb_skip(h, nb);
     }
-    for (uint32_t t = 0; t < nacc; t++) out[i + t] = (uint8_t)(acc >> (8 * t));
+    for (uint32_t t = 0; t < nacc; t++) out[i + t] = (uint8_t)((t < 8 ? acc0 >> (8 * t) : acc1 >> (8 * (t - 8))));
   }
   PROF_MARK(6);
   return bad;

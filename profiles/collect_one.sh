@@ -1,8 +1,8 @@
 #!/bin/bash
-# Runs on the GPU box: one workload of profiles/collect_r04.sh again (bench line + kernel table) into gpurun_out/r04c/.
+# Runs on the GPU box: one workload of profiles/collect_r05.sh again (bench line + kernel table) into gpurun_out/r05c/.
 #   gpurun -- 'bash profiles/collect_one.sh <tag> <bench args ...>'
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r04c
+O=$R/gpurun_out/r05c
 mkdir -p $O
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp

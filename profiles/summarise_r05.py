@@ -60,9 +60,9 @@ if need(f'{O}/pmc_per_kernel.json'):
            "unit": "KB per launch (rocprofv3's unit), average over the launches of the run; per decode call: the sum over all launches of the run divided by its decode calls",
            "note": "gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes for wide coalesced reads (MI355X_MICROARCH.md, HBM): hbm_bytes_x2 doubles it, "
                    "hbm_bytes_raw does not; kernels that read 1-8 bytes per lane (the entropy / token / execution kernels) sit between the two. "
-                   "WRITE_SIZE is exact for 16-byte per-lane stores.  A run makes 3 timed / warm-up decode calls of the whole workload plus the calls of the "
+                   "WRITE_SIZE is exact for 16-byte per-lane stores.  A run makes 4 decode calls of the whole workload (the one behind staging, one warm-up, two timed) plus the call of the "
                    "copy-back sample (up to 4 single stripes): `calls` counts the launches of decompress_finalize_kernel (compressed workloads: one per column lane "
-                   "and call) or summary_to_host_kernel; the per-call totals divide by the 3 full calls after the sample's share (rows) is taken off.",
+                   "and call) or summary_to_host_kernel; the per-call totals divide by the 4 full calls + the sample's share of a call (its rows).",
            "workloads": {}}
     big = pmc.get("lineitem_zstd_sf12_FETCH_SIZE") and pmc.get("lineitem_zstd_sf12_WRITE_SIZE")
     for wl, line_tag in ((("lineitem_zstd_sf12", "lineitem_zstd") if big else ("lineitem_zstd", "lineitem_zstd_sf4")), ("c3_none", "c3_none"), ("c2", "c2")):
@@ -84,12 +84,12 @@ if need(f'{O}/pmc_per_kernel.json'):
             missing.append(f"PMC pass of {wl}: a counter is zero for every kernel (the pass did not run to its end)")
             continue
         rows_full, fetched = L["config"]["rows"], 0
-        # the run: 3 full calls (2 steps + 1 warm-up) + the copy-back sample; weight of the sample = its rows over a full call's rows
+        # the run: 4 full calls (the first decode, 1 warm-up, 2 steps) + the copy-back sample; weight of the sample = its rows over a full call's rows
         sample = 0.0
         if L.get("d2h_fetch_sample"):
             n_s, n_all = [int(x) for x in L["d2h_fetch_sample"].replace(" stripes", "").split(" of ")]
             sample = n_s / max(1, n_all)
-        calls = 3 + sample
+        calls = 4 + sample  # bench.py --steps 2 --warmup 1: the decode behind staging (the checks' input), one warm-up step, two timed steps -- FOUR full calls -- + the copy-back sample.  (summarise_r04.py divided by 3 + sample: its ratios are 4.36 / 3.36 = 1.30 x too high)
         tot_f = sum(v["FETCH_KB_run"] for v in ks.values()) * 1024 / calls
         tot_w = sum(v["WRITE_KB_run"] for v in ks.values()) * 1024 / calls
         algo = L["stream_bytes_in"] + L["arrow_bytes_out"]
