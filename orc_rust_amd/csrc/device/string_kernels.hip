@@ -210,7 +210,7 @@ __device__ __forceinline__ uint32_t dict_valid8(const DictJob& j, uint64_t i, ui
 // Lengths (and dictionary positions) of 8 consecutive rows: keys of the valid ones are consecutive dense values -- for one-byte
 // keys a single 8-byte load.  A key that is no key (out of bounds, or marked impossible by the expansion) yields length 0 and
 // sets bit r of *bad.
-template <bool CACHED>
+template <bool CACHED, bool KEYS = false>
 __device__ __forceinline__ void dict_rows8(const DictJob& j, uint32_t bits, uint64_t d0, uint64_t dict_n, const uint16_t* doffc, uint32_t* len, uint32_t* so,
                                            uint32_t* bad) {
   uint64_t packed = 0;
@@ -235,7 +235,7 @@ __device__ __forceinline__ void dict_rows8(const DictJob& j, uint32_t bits, uint
       continue;
     }
     const uint32_t o = CACHED ? (uint32_t)doffc[key] : (uint32_t)j.doff[key];
-    so[r] = o;
+    so[r] = KEYS ? (uint32_t)key : o;  // (KEYS: the entry's index: dict_emit_small8 reads padded entries)
     len[r] = (CACHED ? (uint32_t)doffc[key + 1] : (uint32_t)j.doff[key + 1]) - o;
   }
 }
@@ -312,6 +312,96 @@ extern "C" __global__ void __launch_bounds__(256) dict_base_kernel(const DictJob
 // of the dictionary -- a thread's rows are one contiguous run of the output --, DICT_CHARS_LDS bytes per round (a row that
 // straddles two rounds is copied in parts), and leave as 16-byte coalesced stores.  Dictionaries too big for LDS, or with
 // entries longer than DICT_STAGE_MAXLEN, go row by row straight from memory to memory.
+// Dictionaries of SHORT entries (eight bytes at most, 1024 entries at most: flags, ship modes, the 7-entry dictionary of BASELINE's
+// C3): the LDS copy of the dictionary is kept PADDED, one aligned 8-byte word per entry, zeros behind its bytes.  A thread's eight
+// rows are one contiguous run of the tile's value bytes: it streams them through a 64-bit accumulator -- entry word shifted in,
+// a full word OR-ed into the (zeroed) LDS stage whenever eight bytes are together -- so a row costs one aligned LDS read, a dozen
+// vector instructions and at most one LDS atomic, where the byte-by-byte copy cost ten LDS operations and their loop for a row of
+// five bytes (C3: 0.42 -> 0.3x ms per 100 M rows; unaligned 8-byte LDS copies were slower than the bytes).  A word may be shared by
+// two threads (a run starts and ends anywhere): every word goes in by ds_or.
+__device__ __forceinline__ void dict_emit_small8(const DictJob& j, uint64_t dict_n, uint8_t* chars, const uint16_t* doffc, const uint64_t* dpad, uint64_t* wsum, uint32_t b,
+                                                 uint32_t tid) {
+  const uint64_t row0 = (uint64_t)b * j.batch;
+  const uint64_t rows = j.n_rows - row0 < j.batch ? j.n_rows - row0 : j.batch;
+  int32_t* out = j.offsets + (uint64_t)b * ((uint64_t)j.batch + 1);
+  uint8_t* cout = j.out_chars ? j.out_chars + j.chartot[j.n_batches + b] : nullptr;
+  unsigned long long* const stage = reinterpret_cast<unsigned long long*>(chars);
+  uint64_t carry = 0;
+  for (uint64_t t0 = 0; t0 < rows; t0 += DICT_TILE) {
+    const uint64_t k = t0 + (uint64_t)tid * DICT_PER;
+    const uint32_t cnt = k < rows ? (rows - k < DICT_PER ? (uint32_t)(rows - k) : DICT_PER) : 0u;
+    uint32_t len[8], key[8], bad;
+    uint64_t d0 = 0;
+    const uint32_t bits = cnt ? dict_valid8(j, row0 + k, cnt, &d0) : 0u;
+    dict_rows8<true, true>(j, bits, d0, dict_n, doffc, len, key, &bad);
+    uint32_t ex[8];
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < 8; r++) {
+      ex[r] = run;
+      run += len[r];
+    }
+    uint32_t incl = run;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o);
+      if ((int)(tid & 63) >= o) incl += t;
+    }
+    __syncthreads();  // (wsum and the stage of the previous tile are no longer read)
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    // the stage, zeroed: 2048 rows of eight bytes at most
+    for (uint32_t q = tid; q < DICT_CHARS_LDS / 16; q += 256) reinterpret_cast<uint4*>(chars)[q] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    uint32_t base = incl - run;
+    for (uint32_t w = 0; w < (tid >> 6); w++) base += (uint32_t)wsum[w];
+    const uint32_t tile_total = (uint32_t)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    if (cnt == DICT_PER) {
+      int32_t o8[8];
+#pragma unroll
+      for (uint32_t r = 0; r < 8; r++) o8[r] = (int32_t)(carry + base + ex[r]);
+      __builtin_memcpy(out + k, o8, 32);
+    } else {
+      for (uint32_t r = 0; r < cnt; r++) out[k + r] = (int32_t)(carry + base + ex[r]);
+    }
+    if (cout && tile_total) {
+      // this thread's bytes: stage bytes [base, base + run).  acc holds the bytes of stage word `word` gathered so far (zeros elsewhere)
+      uint32_t word = base >> 3, fill = base & 7u;
+      uint64_t acc = 0;
+#pragma unroll
+      for (uint32_t r = 0; r < 8; r++) {
+        const uint64_t v = len[r] ? dpad[key[r]] : 0ull;  // (the entry's bytes, zeros behind them)
+        acc |= v << (8u * fill);
+        const uint32_t nf = fill + len[r];
+        if (nf >= 8u) {
+          atomicOr(&stage[word], (unsigned long long)acc);
+          word++;
+          acc = fill ? v >> (8u * (8u - fill)) : 0ull;  // what did not fit (fill = 0: it all did)
+        }
+        fill = nf & 7u;
+      }
+      if (fill) atomicOr(&stage[word], (unsigned long long)acc);
+    }
+    __syncthreads();
+    if (cout && tile_total) {
+      // LDS -> HBM: bytes up to the first 16-byte boundary of the destination one by one, then 16 at a time
+      uint8_t* p8 = cout + carry;
+      const uint32_t n = tile_total;
+      uint32_t head = (uint32_t)((16 - ((uintptr_t)p8 & 15)) & 15);
+      if (head > n) head = n;
+      if (tid < head) p8[tid] = chars[tid];
+      const uint32_t body = (n - head) / 16;
+      for (uint32_t q = tid; q < body; q += 256) {
+        uint64_t v[2];
+        __builtin_memcpy(v, chars + head + q * 16, 16);
+        __builtin_memcpy(p8 + head + (uint64_t)q * 16, v, 16);
+      }
+      const uint32_t done = head + body * 16;
+      if (tid < n - done) p8[done + tid] = chars[done + tid];
+    }
+    carry += tile_total;
+  }
+  if (tid == 0) out[rows] = (int32_t)carry;
+}
+
 template <bool CACHED>
 __device__ __forceinline__ void dict_emit_body(const DictJob& j, uint64_t dict_n, uint8_t* chars, const uint16_t* doffc, const uint8_t* dbc, uint64_t* wsum,
                                                bool staged, uint32_t b, uint32_t tid) {
@@ -450,6 +540,30 @@ extern "C" __global__ void __launch_bounds__(256) dict_emit_kernel(const DictJob
   __syncthreads();
   const bool cached = dict_cache(j, dict_n, doffc, dbc, &maxlen_s, tid);
   __syncthreads();
+  if (cached && maxlen_s <= 8 && dict_n <= DICT_BYTES_LDS / 8) {
+    // short entries: the dictionary copy re-laid as one padded word per entry (read out first: it is rewritten in place)
+    uint64_t pad[DICT_BYTES_LDS / 8 / 256];
+#pragma unroll
+    for (uint32_t q = 0; q < DICT_BYTES_LDS / 8 / 256; q++) {
+      const uint32_t e = tid + 256 * q;
+      pad[q] = 0;
+      if (e < dict_n) {
+        const uint32_t o = doffc[e], l = (uint32_t)doffc[e + 1] - o;
+        uint64_t v;
+        __builtin_memcpy(&v, dbc + o, 8);  // (eight bytes of slack behind the copy)
+        pad[q] = l >= 8 ? v : v & ((1ull << (8 * l)) - 1);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < DICT_BYTES_LDS / 8 / 256; q++) {
+      const uint32_t e = tid + 256 * q;
+      if (e < dict_n) reinterpret_cast<uint64_t*>(dbc)[e] = pad[q];
+    }
+    __syncthreads();
+    dict_emit_small8(j, dict_n, chars, doffc, reinterpret_cast<const uint64_t*>(dbc), wsum, b, tid);
+    return;
+  }
   if (cached) dict_emit_body<true>(j, dict_n, chars, doffc, dbc, wsum, maxlen_s <= DICT_STAGE_MAXLEN, b, tid);
   else dict_emit_body<false>(j, dict_n, chars, doffc, dbc, wsum, false, b, tid);
 }
