@@ -235,8 +235,8 @@ __device__ __forceinline__ int huf_build_dev(uint16_t* tab, int* maxbits_out, ui
 struct HBits {
   const uint8_t* p;
   uint64_t lo, hi1;  // stream bits [wb64 - 64, wb64) and [wb64, wb64 + 64) (the latter kept shifted left by one)
-  uint64_t nx;       // the eight bytes below lo, as loaded: on their way while lo and hi are consumed
-  uint32_t nxs;      // ... and the shift that zeroes what lies before the stream
+  uint64_t nx[4];    // the 32 bytes below lo, highest word first: on their way while lo and hi are consumed
+  uint32_t nxi;      // words of nx taken so far
   int wb64;          // multiple of 8; 0 <= pos - wb64 <= 63 always
   int pos;
 };
@@ -247,21 +247,34 @@ __device__ __forceinline__ uint64_t zl_word(const uint8_t* q, int wb) {
   const int neg = bo < 0 ? -bo : 0;  // bytes of the word that lie before the stream
   return neg >= 8 ? 0ull : v << (8 * neg);
 }
-__device__ __forceinline__ void hb_fetch(HBits& h, int wb) {
-  const int bo = wb >> 3;
-  h.nx = ld_u64(h.p + (bo < 0 ? 0 : bo));
-  h.nxs = bo < 0 ? (uint32_t)(-bo) * 8u : 0u;
+// the four words below bit `wb`: nx[k] = stream bits [wb - 64 (k + 1), wb - 64 k).  ONE 32-byte piece of the stream per 256 bits of
+// codes: with a word at a time (8 bytes per load, 64 lanes 750 bytes apart, 26 wavefronts a CU) every load was a cache line from
+// memory -- the lines do not survive in L2 between a lane's loads: 13.7 GB fetched for 1.1 GB of Huffman streams (PMC, SF 12.5)
+__device__ __forceinline__ void hb_fetch4(HBits& h, int wb) {
+  const int bo = (wb - 256) >> 3;
+  if (bo >= 0) {
+    uint64_t w[4];
+    __builtin_memcpy(w, h.p + bo, 32);
+    h.nx[3] = w[0];
+    h.nx[2] = w[1];
+    h.nx[1] = w[2];
+    h.nx[0] = w[3];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) h.nx[k] = zl_word(h.p, wb - 64 * (k + 1));
+  }
+  h.nxi = 0;
 }
-// A seek costs three loads; stepping down the stream afterwards never waits for memory: the word below the window is requested
-// when the window moves and needed only when it moves again (eight bytes of codes later).  The loop used to reload its window
-// from the cursor's byte position -- a dependent load every five or six symbols in SOME lane of the wavefront, i.e. in every
-// iteration of all of them.
+// A seek costs four loads; stepping down the stream afterwards never waits for memory: the words below the window are requested
+// when the last of them is taken and needed only when the window moves again (eight bytes of codes later).  The loop used to
+// reload its window from the cursor's byte position -- a dependent load every five or six symbols in SOME lane of the wavefront,
+// i.e. in every iteration of all of them.
 __device__ __forceinline__ void hb_seek(HBits& h, int pos) {
   h.pos = pos;
   h.wb64 = (pos & ~7) - 56;
   h.hi1 = zl_word(h.p, h.wb64) << 1;
   h.lo = zl_word(h.p, h.wb64 - 64);
-  hb_fetch(h, h.wb64 - 128);
+  hb_fetch4(h, h.wb64 - 64);
 }
 __device__ __forceinline__ uint32_t hb_peek32(const HBits& h) {  // the 32 bits below pos, bit 31 = the next unread bit
   const uint32_t s = (uint32_t)(h.pos - h.wb64);
@@ -271,9 +284,9 @@ __device__ __forceinline__ void hb_skip(HBits& h, int nb) {
   h.pos -= nb;
   if (h.pos < h.wb64) {
     h.hi1 = h.lo << 1;
-    h.lo = h.nxs >= 64u ? 0ull : h.nx << h.nxs;
+    h.lo = h.nxi == 0 ? h.nx[0] : (h.nxi == 1 ? h.nx[1] : (h.nxi == 2 ? h.nx[2] : h.nx[3]));
     h.wb64 -= 64;
-    hb_fetch(h, h.wb64 - 128);
+    if (++h.nxi == 4) hb_fetch4(h, h.wb64 - 64);
   }
 }
 
@@ -286,7 +299,7 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
     if (!rb_init(r, sp, sn)) bad = 1;
     top = (int)r.bits;
   }
-  HBits h{sp, 0, 0, 0, 0, 0, 0};
+  HBits h{sp, 0, 0, {0, 0, 0, 0}, 0, 0, 0};
   const int B = (top + (int)lps - 1) / (int)lps;
   int pk = top - (int)k * B, pn = k + 1 == lps ? 0 : top - (int)(k + 1) * B;
   if (pk < 0) pk = 0;

@@ -259,6 +259,13 @@ struct orcgpu_ctx {
   orcgpu_lane_stats last_stats{};     // this lane's part of the last call (orcgpu_last_lane_stats)
   uint32_t last_n_lanes = 1;          // lane 0: lanes the last call ran
   double call_t0 = 0;                 // host clock (us) when the call that drives this lane was entered
+  // Zstandard at table scale, several lanes: a lane's sequences kernel takes every CU's LDS (three wavefronts of 52.5 KB); launched
+  // before another lane's FSE table kernel (15 KB a wavefront) it keeps that one out until its own chains end -- the other lane then
+  // starts 4 to 25 ms late (the "straggler" of round 4).  So every lane's table kernel first: a lane launches its sequences kernel
+  // behind the table kernels of ALL lanes.  tables_gate: 0 = this lane has not recorded ev[7] yet, 1 = it has, 2 = it has no such kernel
+  orcgpu_ctx* gate_peers[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  int n_gate_peers = 0;
+  std::atomic<int> tables_gate{0};
   uint32_t last_expand_launches = 0;
   // ---- staging pipeline (lane 0 only): a copy stream, two pinned pieces filled by a few host threads while the other one
   // is on its way to HBM, a pool of stripe arenas ----
