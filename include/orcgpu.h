@@ -75,6 +75,7 @@ enum {
   ORCGPU_ARROW_FLOAT32 = 15, ORCGPU_ARROW_FLOAT64 = 16, ORCGPU_ARROW_UTF8 = 17, ORCGPU_ARROW_BINARY = 18, ORCGPU_ARROW_DATE32 = 19,
   ORCGPU_ARROW_DECIMAL128 = 20,  /* precision / scale in arrow_precision / arrow_scale; (38, 9) is also the wide target of timestamps */
   ORCGPU_ARROW_TIMESTAMP_S_UTC = 21, ORCGPU_ARROW_TIMESTAMP_MS_UTC = 22, ORCGPU_ARROW_TIMESTAMP_US_UTC = 23, ORCGPU_ARROW_TIMESTAMP_NS_UTC = 24,
+  ORCGPU_ARROW_LARGE_UTF8 = 25, ORCGPU_ARROW_LARGE_BINARY = 26,  /* (the encoder's inputs only: i64 offsets) */
   ORCGPU_ARROW_TIMESTAMP_S_NOTZ = 31, ORCGPU_ARROW_TIMESTAMP_MS_NOTZ = 32, ORCGPU_ARROW_TIMESTAMP_US_NOTZ = 33, ORCGPU_ARROW_TIMESTAMP_NS_NOTZ = 34,
   ORCGPU_ARROW_TIMESTAMP_OTHER_TZ = 35,  /* Timestamp(_, Some(tz)) with tz != "UTC": UnsupportedTypeVariant for TimestampInstant */
   /* nested targets (array_decoder/mod.rs:464-505): the hint of a Struct / List / Map / Union column; its children carry theirs */
@@ -382,16 +383,50 @@ const char* orcgpu_reader_column_name(orcgpu_reader* r, uint32_t i);
  * anything else = the OrcError status of the failing batch (the iterator then ends). */
 int orcgpu_reader_next_batch(orcgpu_reader* r, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 
-/* ---- GPU encode: Integer RLE v2 of an Int64 column ---------------------------------------- */
-/* Replaces RleV2Encoder<i64, S>::{write_slice, take_inner} (src/encoding/integer/rle_v2/mod.rs:403-531; the seam is
- * PrimitiveValueEncoder, src/encoding/mod.rs:36-50; a column's encoder is flushed per stripe by src/writer/stripe.rs:109-165):
- * `n` values (host memory) -> the bytes of an RLE v2 stream in `out` (host memory), *out_len of them.  is_signed: zigzag, as the
- * reference's SignedEncoding.  Runs are cut every 512 values -- one wavefront per run -- and take the sub-encoding that fits:
- * SHORT_REPEAT (3..10 equal values), DELTA with a fixed step (an arithmetic progression), else DIRECT at the run's width;
- * PATCHED_BASE is never chosen.  The stream is one valid encoding of the values, not byte for byte the reference encoder's
- * (a greedy state machine over single values); every decoder -- rle_expand.hip, the oracle, the reference -- reads the values back.
- * out = NULL (or out_cap too small: ORCGPU_INVALID_ARGUMENT) only reports the size in *out_len. */
+/* ---- GPU encode: the reference's value encoders, byte for byte ------------------------------ */
+/* Replace RleV2Encoder<N, S>::{write_slice, take_inner} (src/encoding/integer/rle_v2/mod.rs:255-531), ByteRleEncoder
+ * (src/encoding/byte.rs:38-197) and BooleanEncoder (src/encoding/boolean.rs:119-170); the seam is PrimitiveValueEncoder
+ * (src/encoding/mod.rs:36-50); a column's encoders are fed by src/writer/column.rs and flushed per stripe by
+ * src/writer/stripe.rs:109-165.  The bytes are the reference encoder's own: the same runs (its greedy state machine's cuts, found
+ * in parallel: device/rle_encode.hip), the same sub-encoding per run (SHORT_REPEAT / DIRECT / PATCHED_BASE / DELTA by
+ * determine_variable_run_encoding's rules), the same bit widths.  tests/test_gpu_encode.py compares them with the restated
+ * reference encoder (oracle/oo_encode.c).  (On two inputs the reference panics -- oo_encode.c's header --: such runs are DIRECT.)
+ *
+ * values / out: host memory, or device memory with ORCGPU_ENC_ON_DEVICE in flags (then nothing crosses PCIe but the size).
+ * out = NULL only reports the size in *out_len; out_cap too small: ORCGPU_INVALID_ARGUMENT with the size in *out_len.
+ * One call = one stream of a stripe (fewer than 2^32 - 1024 values).  Scratch memory is kept in the context between calls. */
+#define ORCGPU_ENC_ON_DEVICE 1u
+/* n values of int_bytes (2 / 4 / 8: the reference's N = i16 / i32 / i64) each; is_signed: SignedEncoding (zigzag), else UnsignedEncoding */
+int orcgpu_encode_rle2(orcgpu_ctx* ctx, const void* values, uint64_t n, int int_bytes, int is_signed, uint32_t flags, uint8_t* out, uint64_t out_cap,
+                       uint64_t* out_len);
+/* = orcgpu_encode_rle2(ctx, values, n, 8, is_signed, 0, ...) */
 int orcgpu_encode_rle2_i64(orcgpu_ctx* ctx, const int64_t* values, uint64_t n, int is_signed, uint8_t* out, uint64_t out_cap, uint64_t* out_len);
+/* ByteRleEncoder over n bytes (Int8 columns) */
+int orcgpu_encode_byte_rle(orcgpu_ctx* ctx, const void* values, uint64_t n, uint32_t flags, uint8_t* out, uint64_t out_cap, uint64_t* out_len);
+/* BooleanEncoder over an Arrow bitmap of n_bits bits (least significant bit first): PRESENT streams, Boolean DATA */
+int orcgpu_encode_boolean(orcgpu_ctx* ctx, const void* bits, uint64_t n_bits, uint32_t flags, uint8_t* out, uint64_t out_cap, uint64_t* out_len);
+
+/* ColumnStripeEncoder::{encode_array, finish} for one Arrow array = one column of a stripe (src/writer/column.rs:103-165 primitive,
+ * :196-258 Boolean, :304-391 strings / binaries; the types of src/writer/stripe.rs:175-185): only the valid rows' values reach the
+ * encoders, a PRESENT stream is written when the array has a validity bitmap (array.nulls() is Some, whatever it holds).  The
+ * streams come back in the order finish() returns them -- DATA, [LENGTH,] [PRESENT] -- in device memory of the context (valid until
+ * its next encode call; orcgpu_encode_fetch copies one to the host). */
+typedef struct orcgpu_enc_column {
+  int32_t arrow_type;      /* ORCGPU_ARROW_BOOLEAN, _INT8 .. _INT64, _FLOAT32, _FLOAT64, _UTF8, _BINARY, _LARGE_UTF8, _LARGE_BINARY */
+  uint32_t flags;          /* ORCGPU_ENC_ON_DEVICE: the three buffers are device memory */
+  uint64_t n_rows;
+  const uint8_t* validity; /* the validity bitmap, or NULL */
+  const void* values;      /* fixed-width values; Boolean: the value bitmap; strings: value_data */
+  const void* offsets;     /* strings: n_rows + 1 offsets, i32 (i64 for the LARGE_ types) */
+} orcgpu_enc_column;
+typedef struct orcgpu_enc_stream {
+  int32_t kind;            /* ORC stream kind: 0 PRESENT, 1 DATA, 2 LENGTH */
+  uint32_t pad;
+  const uint8_t* data;     /* device memory */
+  uint64_t len;
+} orcgpu_enc_stream;
+int orcgpu_encode_column(orcgpu_ctx* ctx, const orcgpu_enc_column* col, orcgpu_enc_stream streams[3], uint32_t* n_streams);
+int orcgpu_encode_fetch(orcgpu_ctx* ctx, const orcgpu_enc_stream* stream, uint8_t* out);
 
 /* ---- timing hooks used by bench.py (HIP events on the context's own stream) ---------------------- */
 /* Milliseconds the device spent in the last orcgpu_decode_staged call, whole call and the RLE

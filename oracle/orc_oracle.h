@@ -156,4 +156,17 @@ void oo_column_free(oo_column* c);
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- encoders (oo_encode.c): the reference's value encoders restated, for the device encoder's bytes to be compared with ---- */
+/* RleV2Encoder<N, S> (rle_v2/mod.rs:255-420) over n values of N = int_bytes (2 / 4 / 8) wide, held sign-extended; stats (or NULL):
+ * runs written as SHORT_REPEAT, DIRECT, PATCHED_BASE, DELTA, and [4] the runs on which the reference panics (written DIRECT) */
+int oo_enc_rle2(const int64_t* vals, uint64_t n, int int_bytes, int is_signed, uint8_t** out, uint64_t* out_len, uint64_t* stats);
+/* determine_variable_run_encoding alone (rle_v2/mod.rs:422-531) */
+int oo_enc_rle2_variable_run(const int64_t* lit, uint32_t n, int int_bytes, int is_signed, uint8_t** out, uint64_t* out_len);
+/* ByteRleEncoder (byte.rs:38-197) */
+int oo_enc_byte_rle(const uint8_t* vals, uint64_t n, uint8_t** out, uint64_t* out_len);
+/* BooleanEncoder::finish (boolean.rs:157-169) over an Arrow bitmap (least significant bit first) */
+int oo_enc_boolean(const uint8_t* bits_lsb, uint64_t n_bits, uint8_t** out, uint64_t* out_len);
+void oo_enc_free(void* p);
+
 #endif

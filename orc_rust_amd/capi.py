@@ -20,7 +20,7 @@ EXPORTS = [
     "orcgpu_open", "orcgpu_close", "orcgpu_last_error", "orcgpu_version", "orcgpu_stage_stripe", "orcgpu_staged_free",
     "orcgpu_staged_bytes", "orcgpu_decode_staged", "orcgpu_stripe_decode", "orcgpu_result_free", "orcgpu_result_status",
     "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
-    "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_fetch_async", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_timezone_offsets", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms", "orcgpu_last_lane_stats", "orcgpu_encode_rle2_i64",
+    "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_fetch_async", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_timezone_offsets", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms", "orcgpu_last_lane_stats", "orcgpu_encode_rle2_i64", "orcgpu_encode_rle2", "orcgpu_encode_byte_rle", "orcgpu_encode_boolean", "orcgpu_encode_column", "orcgpu_encode_fetch",
     "orcgpu_reader_open_file", "orcgpu_reader_open_bytes", "orcgpu_reader_close", "orcgpu_reader_set_batch_size",
     "orcgpu_reader_set_projection", "orcgpu_reader_set_projection_roots", "orcgpu_reader_set_schema", "orcgpu_reader_set_byte_range", "orcgpu_reader_set_shard", "orcgpu_shard_columns", "orcgpu_reader_column_weight", "orcgpu_reader_set_timestamp_precision", "orcgpu_reader_set_row_selection", "orcgpu_reader_set_prefetch",
     "orcgpu_reader_set_row_group_pruning", "orcgpu_reader_row_groups", "orcgpu_index_entry", "orcgpu_reader_set_predicate",
@@ -101,6 +101,20 @@ def timezone_offsets(name, instants):
     return out, epoch.value
 
 
+class EncColumn(C.Structure):
+    _fields_ = [("arrow_type", C.c_int32), ("flags", C.c_uint32), ("n_rows", C.c_uint64), ("validity", C.c_void_p), ("values", C.c_void_p),
+                ("offsets", C.c_void_p)]
+
+
+class EncStream(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pad", C.c_uint32), ("data", C.c_void_p), ("len", C.c_uint64)]
+
+
+ENC_ON_DEVICE = 1
+ARROW = {"bool": 10, "int8": 11, "int16": 12, "int32": 13, "int64": 14, "float32": 15, "float64": 16, "utf8": 17, "binary": 18,
+         "large_utf8": 25, "large_binary": 26}
+
+
 class BatchView(C.Structure):
     _fields_ = [("length", C.c_uint64), ("null_count", C.c_uint64), ("validity", C.c_void_p), ("values", C.c_void_p),
                 ("values_bytes", C.c_uint64), ("offsets", C.c_void_p)]
@@ -172,6 +186,11 @@ def load():
     L.orcgpu_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
     L.orcgpu_last_lane_stats.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(LaneStats)]
     L.orcgpu_encode_rle2_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.orcgpu_encode_rle2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.orcgpu_encode_byte_rle.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.orcgpu_encode_boolean.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.orcgpu_encode_column.argtypes = [C.c_void_p, C.POINTER(EncColumn), C.POINTER(EncStream), C.POINTER(C.c_uint32)]
+    L.orcgpu_encode_fetch.argtypes = [C.c_void_p, C.POINTER(EncStream), C.c_void_p]
     L.orcgpu_reader_open_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
     L.orcgpu_reader_open_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]
     L.orcgpu_reader_close.argtypes = [C.c_void_p]
@@ -265,6 +284,55 @@ class Context:
         out = C.c_void_p()
         self._check(self.L.orcgpu_stage_stripe(self.h, C.byref(d), C.byref(out)))
         return Staged(self, out.value)
+
+    def _encode(self, fn, *args):
+        """size first, then the bytes (the two-call protocol of the orcgpu_encode_* entry points)"""
+        n = C.c_uint64(0)
+        self._check(fn(self.h, *args, None, 0, C.byref(n)))
+        out = np.zeros(max(1, n.value), dtype=np.uint8)
+        m = C.c_uint64(0)
+        self._check(fn(self.h, *args, out.ctypes.data, out.size, C.byref(m)))
+        assert m.value == n.value
+        return out[:n.value].tobytes()
+
+    def encode_rle2(self, values, int_bytes=8, signed=True):
+        """RleV2Encoder<N, S> (rle_v2/mod.rs:255-531) over host values of N = int_bytes"""
+        v = np.ascontiguousarray(values, dtype={2: np.int16, 4: np.int32, 8: np.int64}[int_bytes])
+        return self._encode(self.L.orcgpu_encode_rle2, v.ctypes.data, v.size, int_bytes, 1 if signed else 0, 0)
+
+    def encode_byte_rle(self, values):
+        v = np.ascontiguousarray(values).view(np.uint8)
+        return self._encode(self.L.orcgpu_encode_byte_rle, v.ctypes.data, v.size, 0)
+
+    def encode_boolean(self, bits_lsb, n_bits):
+        v = np.ascontiguousarray(bits_lsb, dtype=np.uint8)
+        assert v.size * 8 >= n_bits
+        return self._encode(self.L.orcgpu_encode_boolean, v.ctypes.data, n_bits, 0)
+
+    def encode_column(self, arrow_type, n_rows, values, validity=None, offsets=None):
+        """ColumnStripeEncoder::{encode_array, finish} (writer/column.rs): [(ORC stream kind, bytes)] in finish()'s order"""
+        keep = [np.ascontiguousarray(values)]
+        col = EncColumn(ARROW[arrow_type], 0, n_rows, None, keep[0].ctypes.data if keep[0].size else None, None)
+        if keep[0].size == 0:
+            keep.append(np.zeros(1, dtype=np.uint8))
+            col.values = keep[-1].ctypes.data
+        if validity is not None:
+            keep.append(np.ascontiguousarray(validity, dtype=np.uint8))
+            if keep[-1].size == 0:
+                keep[-1] = np.zeros(1, dtype=np.uint8)
+            col.validity = keep[-1].ctypes.data
+        if offsets is not None:
+            keep.append(np.ascontiguousarray(offsets))
+            col.offsets = keep[-1].ctypes.data
+        streams = (EncStream * 3)()
+        n = C.c_uint32(0)
+        self._check(self.L.orcgpu_encode_column(self.h, C.byref(col), streams, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            buf = np.zeros(max(1, streams[i].len), dtype=np.uint8)
+            self._check(self.L.orcgpu_encode_fetch(self.h, C.byref(streams[i]), buf.ctypes.data))
+            out.append((streams[i].kind, buf[:streams[i].len].tobytes()))
+        return out
 
     def decode(self, staged_list, results=None):
         n = len(staged_list)

@@ -244,6 +244,7 @@ struct orcgpu_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   DevBuf scratch;
+  DevBuf enc_a, enc_b, enc_in, enc_tmp, enc_out[3];  // the encoder's own (orcgpu_encode.inc): chain tables, run tables, inputs brought to the device, gathered values, streams
   uint8_t* pinned = nullptr;
   size_t pinned_cap = 0;
   uint8_t* fin_pinned = nullptr;       // staging of the finishers' job table
@@ -775,6 +776,11 @@ void orcgpu_close(orcgpu_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->scratch.release();
+  c->enc_a.release();
+  c->enc_b.release();
+  c->enc_in.release();
+  c->enc_tmp.release();
+  for (auto& b : c->enc_out) b.release();
   delete c->copiers;
   for (int k = 0; k < 2; k++) {
     if (c->piece[k]) (void)hipHostFree(c->piece[k]);

@@ -18,7 +18,7 @@ COMP = {"none": 0, "zlib": 1, "snappy": 2, "lzo": 3, "lz4": 4, "zstd": 5}
 
 
 def build():
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oo_codecs.c", "oo_encoding.c", "oo_column.c", "orc_oracle.h")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oo_codecs.c", "oo_encoding.c", "oo_column.c", "oo_encode.c", "orc_oracle.h")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liborc_oracle.so"])
     return _SO
@@ -87,8 +87,53 @@ def lib():
         L.oo_timestamps_to_utc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p]
         L.oo_timestamp_decimals_to_utc.restype = None
         L.oo_timestamp_decimals_to_utc.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int64]
+        L.oo_enc_rle2.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]
+        L.oo_enc_rle2_variable_run.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.oo_enc_byte_rle.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.oo_enc_boolean.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.oo_enc_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
+
+
+def _enc_result(st, out, n):
+    assert st == 0, st
+    res = C.string_at(out, n.value) if n.value else b""
+    lib().oo_enc_free(out)
+    return res
+
+
+def enc_rle2(values, int_bytes=8, signed=True, with_stats=False):
+    """The reference's RleV2Encoder<N, S> over `values` (N = int_bytes wide): its bytes [, runs per sub-encoding + reference panics]."""
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    out, n = C.c_void_p(), C.c_uint64()
+    stats = np.zeros(5, dtype=np.uint64)
+    st = lib().oo_enc_rle2(v.ctypes.data, len(v), int_bytes, int(signed), C.byref(out), C.byref(n), stats.ctypes.data)
+    res = _enc_result(st, out, n)
+    return (res, stats) if with_stats else res
+
+
+def enc_rle2_variable_run(literals, int_bytes=8, signed=True):
+    v = np.ascontiguousarray(literals, dtype=np.int64)
+    out, n = C.c_void_p(), C.c_uint64()
+    st = lib().oo_enc_rle2_variable_run(v.ctypes.data, len(v), int_bytes, int(signed), C.byref(out), C.byref(n))
+    return _enc_result(st, out, n)
+
+
+def enc_byte_rle(values):
+    v = np.ascontiguousarray(values).view(np.uint8)
+    out, n = C.c_void_p(), C.c_uint64()
+    st = lib().oo_enc_byte_rle(v.ctypes.data, len(v), C.byref(out), C.byref(n))
+    return _enc_result(st, out, n)
+
+
+def enc_boolean(bits_lsb, n_bits):
+    """bits_lsb: an Arrow bitmap (numpy uint8, least significant bit first) of n_bits bits"""
+    v = np.ascontiguousarray(bits_lsb, dtype=np.uint8)
+    assert len(v) * 8 >= n_bits
+    out, n = C.c_void_p(), C.c_uint64()
+    st = lib().oo_enc_boolean(v.ctypes.data, n_bits, C.byref(out), C.byref(n))
+    return _enc_result(st, out, n)
 
 
 def codec(name, data, cap):
