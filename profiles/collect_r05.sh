@@ -35,14 +35,20 @@ for c in none snappy; do run c3_${c}_index --workload c3 --compression $c --row-
 run c5_lz4 --workload c5 --compression lz4
 # 3b. the timeline of one headline step (kernel, queue, start, end): what runs beside what
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/raw_trace -- python3 $R/bench.py --steps 4 --warmup 3 --no-cpu --skip-check --no-e2e > /dev/null 2> $O/prof_trace.err )
-python3 profiles/timeline.py $O/raw_trace 30 > $O/timeline_lineitem_zstd.txt 2>&1
+python3 $R/profiles/timeline.py $O/raw_trace 30 > $O/timeline_lineitem_zstd.txt 2>&1
 ( cd /tmp && ORCGPU_LANES=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/raw_trace1 -- python3 $R/bench.py --steps 4 --warmup 3 --no-cpu --skip-check --no-e2e > /dev/null 2> $O/prof_trace1.err )
-python3 profiles/timeline.py $O/raw_trace1 30 > $O/timeline_lineitem_zstd_one_lane.txt 2>&1
+python3 $R/profiles/timeline.py $O/raw_trace1 30 > $O/timeline_lineitem_zstd_one_lane.txt 2>&1
 rm -rf $O/raw_trace1
 rm -rf $O/raw_trace
 # 3c. what a row selection / a predicate costs with row-group pruning; the reader's own rate
 ( cd $R && timeout 600 python profiles/select_cost.py 24000000 > $O/select_cost.json 2> $O/select_cost.err )
 ( cd $R && timeout 600 python profiles/reader_rate.py 24000000 > $O/reader_rate.json 2> $O/reader_rate.err )
+# 3d. the device encoders (8(f)-4): rate on device-resident Int64 columns, and their kernel table
+( cd $R && timeout 600 python profiles/encode_rate.py 48000000 > $O/encode_rate.json 2> $O/encode_rate.err )
+( cd $R && timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw_encode -- python3 profiles/encode_rate.py 16000000 > /dev/null 2> $O/prof_encode.err )
+f=$(find $O/raw_encode -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp "$f" $O/kernel_stats_encode.csv
+rm -rf $O/raw_encode
 # 4. HBM traffic of the headline (SF 4: the table-scale kernels, 11 stripes) and of C3 / C2: FETCH_SIZE and WRITE_SIZE in passes of
 #    their own (no trace domain beside --kernel-trace), each bounded
 pmc() {  # tag, counter, bench args...

@@ -36,9 +36,11 @@ for f in sorted(glob.glob(f'{O}/sf_*.json'), key=lambda f: float(os.path.basenam
                   "mrows_per_s": d["mrows_per_s"], "ms_per_step": d["ms_per_step"], "phase_ms": d["phase_ms"], "roofline_kernel": (d["roofline"]["kernel"] or "-").split(" ")[0],
                   "roofline_frac": d["roofline"]["frac"], "whole_step_frac": d["roofline"]["whole_step_frac"], "generate_s": d["setup"]["generate_s"]})
 json.dump({"command": "python bench.py --sf <SF> --steps 5 --warmup 2 --no-cpu --no-e2e", "curve": curve}, open(f'{P}/r05_sf_curve.json', 'w'), indent=1)
-for name in ("select_cost", "reader_rate"):
+for name in ("select_cost", "reader_rate", "encode_rate"):
     if need(f'{O}/{name}.json'):
         json.dump(json.loads(open(f'{O}/{name}.json').read()), open(f'{P}/r05_{name}.json', 'w'), indent=1)
+if need(f'{O}/kernel_stats_encode.csv'):
+    shutil.copy(f'{O}/kernel_stats_encode.csv', f'{P}/r05_encode_kernel_stats.csv')
 for tl in ("timeline_lineitem_zstd", "timeline_lineitem_zstd_one_lane"):
     if need(f'{O}/{tl}.txt'):
         shutil.copy(f'{O}/{tl}.txt', f'{P}/r05_{tl}.txt')
