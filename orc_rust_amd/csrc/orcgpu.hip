@@ -249,7 +249,7 @@ struct orcgpu_ctx {
   size_t pinned_cap = 0;
   uint8_t* fin_pinned = nullptr;       // staging of the finishers' job table
   size_t fin_pinned_cap = 0;
-  hipEvent_t ev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk, after the decompressors' first stage, in front of the Zstandard sequences kernel (one lane per block), behind it
+  hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start, before / after expansion, end, after decompression, after the walk, after the decompressors' first stage, behind the Zstandard table kernel, behind the sequences kernel (one lane per block), [9] in front of it (behind the wait for the other lanes' table kernels)
   uint32_t n_cus = 0;
   hipEvent_t kev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // around rle_walk_short_kernel [0] and dict_emit_kernel [1] (orcgpu_last_lane_stats)
   bool kev_used[2] = {false, false};

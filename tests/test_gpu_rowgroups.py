@@ -209,6 +209,44 @@ def test_structs_and_unusable_indexes(tmp_path):
     check(nul, path, sel, expect_pruned=False)
 
 
+def test_lists_and_maps_are_pruned_like_flat_columns(tmp_path):
+    """Stripes with List / Map columns (round 5): the LENGTH stream is entered at the row group's position like any RLE stream, the
+    elements' streams at the positions their own index entries hold for the same row group (list.rs:89, map.rs:106 step a
+    selection through the nested decoders); how many elements a piece holds follows from its lengths."""
+    n = 60_000
+    rng = np.random.default_rng(23)
+    def lists(values, max_len, null_frac):
+        lens = rng.integers(0, max_len + 1, n)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        return pa.ListArray.from_arrays(pa.array(offs), values(int(offs[-1])), mask=pa.array(rng.random(n) < null_frac) if null_frac else None)
+    ints = lists(lambda m: pa.array(rng.integers(-2**40, 2**40, m), mask=rng.random(m) < 0.1), 6, 0.15)
+    strs = lists(lambda m: pa.array(["e%d" % (i % 311) for i in range(m)]), 4, 0.0)
+    nested = lists(lambda m: pa.ListArray.from_arrays(pa.array(np.arange(m + 1, dtype=np.int32) * 2), pa.array(rng.integers(0, 9, 2 * m).astype(np.int16))), 3, 0.05)
+    mlens = rng.integers(0, 4, n)
+    moffs = np.concatenate([[0], np.cumsum(mlens)]).astype(np.int32)
+    m = int(moffs[-1])
+    maps = pa.MapArray.from_arrays(pa.array(moffs), pa.array(["k%d" % (i % 17) for i in range(m)]), pa.array(rng.integers(0, 1 << 20, m), mask=rng.random(m) < 0.2))
+    table = pa.table({"id": pa.array(np.arange(n, dtype=np.int64)), "ints": ints, "strs": strs, "nested": nested, "maps": maps})
+    sel = [S(17_500), K(600), S(20_000), K(1), S(999), K(1200), S(n - 17_500 - 600 - 20_000 - 1 - 999 - 1200)]
+    for comp, block in (("uncompressed", 65536), ("zstd", 65536), ("snappy", 65536)):
+        path = write(tmp_path, table, "l_%s.orc" % comp, compression=comp, compression_block_size=block, row_index_stride=1000, stripe_size=64 << 20)
+        assert len(stripe_rows(path)) == 1
+        # elements with nulls (`ints`, the values of `maps`): their PRESENT streams are entered in mid-byte at most row groups -- such a
+        # projection is decoded whole, with the same batches
+        check(table, path, sel, batch_size=700, expect_pruned=False)
+        g_read, g_total = check(table, path, sel, batch_size=700, names=["id", "strs", "nested"])
+        assert g_read < g_total == 60, (g_read, g_total)
+        g_read, g_total = check(table, path, [S(59_990), K(10)], names=["nested"])
+        assert g_read == 1, (g_read, g_total)
+    # a Map without null values, Lists with null rows but whole elements
+    maps2 = pa.MapArray.from_arrays(pa.array(moffs), pa.array(["k%d" % (i % 17) for i in range(m)]), pa.array(rng.integers(0, 1 << 20, m)))
+    ints2 = lists(lambda k: pa.array(rng.integers(-2**40, 2**40, k)), 6, 0.15)
+    t2 = pa.table({"id": table["id"], "maps": maps2, "ints": ints2})
+    path = write(tmp_path, t2, "m2.orc", compression="zstd", compression_block_size=65536, row_index_stride=1000, stripe_size=64 << 20)
+    g_read, g_total = check(t2, path, sel, batch_size=700)
+    assert g_read < g_total, (g_read, g_total)
+
+
 def test_reference_fixtures_with_and_without_index():
     """TestOrcFile.testSeek.orc / testWithoutIndex.orc (the reference's fixtures): selections over their flat columns."""
     import arrow_util as A
