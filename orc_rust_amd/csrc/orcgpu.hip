@@ -729,13 +729,24 @@ extern "C" {
 
 const char* orcgpu_version(void) { return "orcgpu 0.1 (gfx950)"; }
 
-orcgpu_ctx* orcgpu_open(int device, const orcgpu_opts* opts) {
+// `lane` > 0: the context of a column lane beside the caller's own (orcgpu_decode.inc).  The caller's own stream -- lane 0, which takes
+// the columns with the longest Zstandard chains -- is created at the highest stream priority: its sequences kernel lasts as long as
+// its longest chain, and beside another lane's sequences kernel (both hold three wavefronts' worth of LDS per CU) it got half the
+// slots and started its long chains late (its span 14.5 -> 9.1 ms, the step 41.3 -> 40.6 ms).  ORCGPU_LANE_PRIORITY (development):
+// bit 0 -- the later lanes' streams at the lowest priority, bit 1 -- their second streams too, bit 2 -- lane 0's stream at the
+// highest (the default: 4), bit 3 -- its second stream too
+static orcgpu_ctx* open_ctx(int device, const orcgpu_opts* opts, int lane) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   orcgpu_ctx* c = new orcgpu_ctx();
   c->device = device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  static const int lane_prio = getenv("ORCGPU_LANE_PRIORITY") ? atoi(getenv("ORCGPU_LANE_PRIORITY")) : 4;
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  const bool low = lane > 0 && (lane_prio & 1), low_aux = lane > 0 && (lane_prio & 2);
+  const bool high = lane == 0 && (lane_prio & 4), high_aux = lane == 0 && (lane_prio & 8);
+  if ((low || high ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, low ? least : greatest) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
     delete c;
     return nullptr;
   }
@@ -755,7 +766,7 @@ orcgpu_ctx* orcgpu_open(int device, const orcgpu_opts* opts) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = (uint32_t)prop.multiProcessorCount;
   }
   // (without these the Zstandard stages simply run one after the other)
-  if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) c->aux_stream = nullptr;
+  if ((low_aux || high_aux ? hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, low_aux ? least : greatest) : hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)) != hipSuccess) c->aux_stream = nullptr;
   for (auto& e : c->aux_ev)
     if (c->aux_stream && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
       (void)hipStreamDestroy(c->aux_stream);
@@ -765,6 +776,7 @@ orcgpu_ctx* orcgpu_open(int device, const orcgpu_opts* opts) {
   c->lanes[0] = c;
   return c;
 }
+orcgpu_ctx* orcgpu_open(int device, const orcgpu_opts* opts) { return open_ctx(device, opts, 0); }
 
 void orcgpu_close(orcgpu_ctx* c) {
   if (!c) return;
