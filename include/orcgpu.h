@@ -115,7 +115,7 @@ typedef struct {
    * stream).  Dictionary streams (DICTIONARY_DATA, the LENGTH stream of a dictionary) are always given whole.  The bytes may
    * reach beyond what the rows need: what lies behind the values the stripe's rows consume is not looked at. */
   uint32_t skip_bytes;
-  uint32_t skip_values; /* PRESENT / Boolean DATA: in bytes of the bit stream (the entry's bit offset must be 0) */
+  uint32_t skip_values; /* PRESENT / Boolean DATA: in bytes of the bit stream; the bits of the byte there already consumed: skip_bits below */
   /* Optional (NULL, 0: none): where the stripe's later row groups start in this stream, in stream order, chunk_offset counted
    * from `ptr` -- the ROW_INDEX positions of the stream.  Run-length streams use them as verified run starts: one lane per
    * row group follows the run headers from its entry to the next (some tens of dependent steps instead of the whole stream's),
@@ -123,6 +123,7 @@ typedef struct {
    * them.  Only a hint: entries that do not lie on the stream's run chain are noticed and ignored. */
   const orcgpu_stream_entry* entries;
   uint32_t n_entries;
+  uint32_t skip_bits;   /* PRESENT / Boolean DATA entered at a row group: bits (0..7) of the first byte that belong to the rows before */
 } orcgpu_stream;
 
 /* One projected leaf column: what Column / DataType / ColumnEncoding carry (src/column.rs:24-59). */

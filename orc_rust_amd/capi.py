@@ -42,7 +42,7 @@ class StreamEntry(C.Structure):
 
 class Stream(C.Structure):
     _fields_ = [("column_id", C.c_uint32), ("kind", C.c_int32), ("ptr", C.c_void_p), ("len", C.c_uint64),
-                ("skip_bytes", C.c_uint32), ("skip_values", C.c_uint32), ("entries", C.c_void_p), ("n_entries", C.c_uint32)]
+                ("skip_bytes", C.c_uint32), ("skip_values", C.c_uint32), ("entries", C.c_void_p), ("n_entries", C.c_uint32), ("skip_bits", C.c_uint32)]
 
 
 class Column(C.Structure):

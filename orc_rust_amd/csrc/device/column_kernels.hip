@@ -42,6 +42,9 @@ struct PresJob {
   // parent_rank are then the Union's own words and ranks, null when it has no nulls)
   const int8_t* tags;
   int32_t tag;
+  // streams entered at a row group in mid-byte (orcgpu_stream::skip_bits): bits of the first byte of this column's PRESENT stream
+  // that belong to the rows before (bit0), of its Boolean DATA stream (data_bits), of its fields' PRESENT streams (child_bits)
+  uint32_t bit0, data_bits, child_bits;
 };
 
 __device__ __forceinline__ void present_word(const PresJob& j, uint64_t w) {
@@ -61,9 +64,11 @@ __device__ __forceinline__ void present_word(const PresJob& j, uint64_t w) {
     uint64_t x = ld_u64(j.pbytes + w * 8);
     // reverse the bits inside each byte: bitreverse64 reverses everything, bswap restores byte order
     v = __builtin_bswap64(__builtin_bitreverse64(x));
+    if (j.bit0) v = (v >> j.bit0) | (__builtin_bswap64(__builtin_bitreverse64(ld_u64(j.pbytes + w * 8 + 8))) << (64 - j.bit0));  // (slack behind the stream)
     const unsigned long long e = j.job->err;
     if (e != RLE_NO_ERR) {
-      const uint64_t bits = (e >> 8) * 8;
+      const uint64_t got = (e >> 8) * 8;
+      const uint64_t bits = got > j.bit0 ? got - j.bit0 : 0;
       if (bits < j.n_rows) {
         const uint64_t cutoff = bits / j.batch * j.batch;  // first row of the batch that fails
         if (w * 64 + 64 > cutoff) v |= w * 64 >= cutoff ? ~0ull : ~0ull << (cutoff - w * 64);
@@ -75,14 +80,14 @@ __device__ __forceinline__ void present_word(const PresJob& j, uint64_t w) {
       v = pv;  // no PRESENT stream of its own: null exactly where the parent is (derive_present_vec: (None, Some(parent)))
     } else {
       // the column's bits for this word: popcount(pv) of them, from bit parent_rank[w] of its own stream on
-      const uint64_t r = j.parent_rank[w];
+      const uint64_t r = (uint64_t)j.parent_rank[w] + j.bit0;
       const uint64_t a = __builtin_bswap64(__builtin_bitreverse64(ld_u64(j.pbytes + (r >> 3))));
       const uint64_t b = __builtin_bswap64(__builtin_bitreverse64(ld_u64(j.pbytes + (r >> 3) + 8)));  // (slack behind the stream)
       const uint32_t sh = (uint32_t)(r & 7);
       unsigned long long c = sh ? (a >> sh) | (b << (64 - sh)) : a;
       const unsigned long long e = j.job->err;
       if (e != RLE_NO_ERR) {  // (the stream failed to decode: the bits it did not deliver read as present, like a root column's)
-        const uint64_t bits = (e >> 8) * 8;
+        const uint64_t bits = (e >> 8) * 8;  // (counted from the stream's first byte, like r)
         if (bits < r + 64) c |= bits <= r ? ~0ull : ~0ull << (bits - r);
       }
       // deal them out to the set bits of the parent's word, lowest first
@@ -156,8 +161,8 @@ extern "C" __global__ void __launch_bounds__(256) pres_scan_sums_kernel(const Pr
   }
   if (threadIdx.x == 0) {
     *j.nonnull_out = carry_s;
-    if (j.ceil8_out) *j.ceil8_out = (carry_s + 7) / 8;
-    if (j.ceil8b_out) *j.ceil8b_out = (carry_s + 7) / 8;
+    if (j.ceil8_out) *j.ceil8_out = (carry_s + j.data_bits + 7) / 8;
+    if (j.ceil8b_out) *j.ceil8b_out = (carry_s + j.child_bits + 7) / 8;
   }
 }
 extern "C" __global__ void __launch_bounds__(256) pres_scan_apply_kernel(const PresJob* jobs) {
@@ -316,7 +321,7 @@ __device__ __forceinline__ void copy_bytes_body(const uint8_t* src, uint8_t* dst
 // deposited into the valid positions.
 __device__ __forceinline__ void bool_values_body(const uint8_t* dbytes, const unsigned long long* vbits, const uint32_t* rank,
                                                                       uint64_t n_rows, uint32_t batch, uint32_t words_per_batch,
-                                                                      unsigned long long* out, uint64_t n_out_words) {
+                                                                      unsigned long long* out, uint64_t n_out_words, uint32_t bit0) {
   uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = t < n_out_words;
   if (!live) t = n_out_words - 1;  // stays in the wavefront for the reduction below, contributes nothing
@@ -331,12 +336,14 @@ __device__ __forceinline__ void bool_values_body(const uint8_t* dbytes, const un
       uint64_t row = row0 + k;
       uint64_t d = row;
       bool valid = true;
+      // (bit0: a stream entered at a row group in mid-byte -- the bits of its first byte that belong to the rows before)
       if (vbits) {
         unsigned long long word = vbits[row >> 6];
         uint32_t bit = row & 63;
         valid = (word >> bit) & 1;
         d = (uint64_t)rank[row >> 6] + __builtin_popcountll(word & ((1ull << bit) - 1));
       }
+      d += bit0;
       if (valid && ((dbytes[d >> 3] >> (7 - (d & 7))) & 1)) v |= 1ull << k;
     }
   }

@@ -365,7 +365,6 @@ __device__ __forceinline__ EncVals enc_load_run(const void* values, int int_byte
   return e;
 }
 
-#define ENC_RUNS_PER_WAVE 4u
 
 // PATCHED_BASE's patch list (derive_patches, patched_base.rs:162-226): the indexes of the values above `mask`, in order, into
 // idx[] (LDS of this wavefront); returns how many.  flags: bit i = this lane's value i is patched.
@@ -386,20 +385,151 @@ __device__ __forceinline__ uint32_t enc_patch_indexes(uint32_t* idx, uint32_t fl
   return total;
 }
 
-// 4a. determine_variable_run_encoding (rle_v2/mod.rs:422-531) per run, a wavefront at a time
+// 4a. what a run is written as.  A wavefront takes 64 runs: runs of repeats (SHORT_REPEAT, a DELTA of step 0: rle_v2/mod.rs:303-337,
+// :361-384) and literals of up to three values (DIRECT, :426-432) are settled by their lane alone; longer literals take the
+// wavefront, one run after the other -- determine_variable_run_encoding (rle_v2/mod.rs:422-531) with lane l holding values
+// 8 l .. 8 l + 7 of the run.
+__device__ __forceinline__ void enc2_plan_coop(const void* values, int int_bytes, uint32_t nbits, int is_signed, uint32_t start, uint32_t len, uint32_t lane,
+                                               uint32_t* hist, uint32_t* idx, EncRun& rec, uint32_t& bytes) {
+  const EncVals e = enc_load_run(values, int_bytes, start, len, lane);
+  int64_t zz[8];
+  uint32_t zbits = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    zz[i] = enc_zigzag_n(e.v[i], nbits, is_signed);
+    if ((uint32_t)i < e.cnt) {
+      const uint32_t b = enc_bits_n(zz[i], nbits);
+      zbits = b > zbits ? b : zbits;
+    }
+  }
+  zbits = wave_max_u32(zbits);
+  const uint32_t direct_w = enc_aligned_bits(zbits);
+  rec.mode = 1;
+  rec.w = (uint8_t)direct_w;
+  bytes = 2 + (len * direct_w + 7) / 8;
+  // delta_encoding_check (rle_v2/mod.rs:186-239)
+  const int64_t v0 = (int64_t)__shfl((long long)e.v[0], 0), v1 = (int64_t)__shfl((long long)e.v[1], 0);
+  const int64_t first_delta = enc_sat_sub(v1, v0);
+  const int64_t below = (int64_t)__shfl_up((long long)e.v[7], 1);
+  int64_t mn = INT64_MAX, mx = INT64_MIN, maxd = 0;
+  bool inc = true, dec = true, fx = true;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if ((uint32_t)i < e.cnt) {
+      mn = e.v[i] < mn ? e.v[i] : mn;
+      mx = e.v[i] > mx ? e.v[i] : mx;
+      const uint32_t gi = lane * 8 + i;
+      if (gi >= 2) {
+        const int64_t cur = enc_sat_sub(e.v[i], i ? e.v[i ? i - 1 : 0] : below);
+        inc = inc && cur >= 0;
+        dec = dec && cur <= 0;
+        fx = fx && cur == first_delta;
+        const int64_t a = enc_sat_abs(cur);
+        maxd = a > maxd ? a : maxd;
+      }
+    }
+  }
+  mn = wave_min_i64(mn);
+  mx = wave_max_i64(mx);
+  maxd = wave_max_i64(maxd);
+  const bool is_inc = first_delta > 0 && !__ballot(!inc), is_dec = first_delta < 0 && !__ballot(!dec), is_fixed = !__ballot(!fx);
+  int64_t range;
+  bool ovf = __builtin_sub_overflow(mx, mn, &range);
+  if (!ovf && nbits < 64) ovf = range >= ((int64_t)1 << (nbits - 1));
+  const int64_t zbase = enc_zigzag_n(v0, nbits, is_signed);
+  const int64_t zfirst = enc_zigzag_n(first_delta, 64, 1);
+  if (ovf) return;  // DIRECT
+  if (is_fixed) {
+    rec.mode = 3;
+    rec.w = 0;
+    bytes = 2 + enc_varint_len(zbase, nbits) + enc_varint_len(zfirst, 64);
+    return;
+  }
+  if (first_delta != 0 && (is_inc || is_dec)) {
+    uint32_t w = enc_aligned_bits(enc_bits_n(maxd, 64));
+    w = w == 1 ? 2 : w;
+    rec.mode = 4;
+    rec.w = (uint8_t)w;
+    bytes = 2 + enc_varint_len(zbase, nbits) + enc_varint_len(zfirst, 64) + ((len - 2) * w + 7) / 8;
+    return;
+  }
+  if (mn != INT64_MIN && (mn < 0 ? -mn : mn) >= ((int64_t)1 << 56)) return;  // DIRECT
+  uint32_t code[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) code[i] = enc_width_code(enc_bits_n(zz[i], nbits));
+  enc_hist(hist, code, e.cnt, lane);
+  const uint32_t z90 = enc_percentile(hist, len, 0.90f), z100 = enc_percentile(hist, len, 1.00f);
+  __builtin_amdgcn_wave_barrier();
+  if (z100 <= z90 + 1) return;  // DIRECT
+  int64_t brl[8], maxb = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    brl[i] = (uint32_t)i < e.cnt ? e.v[i] - mn : 0;
+    maxb = brl[i] > maxb ? brl[i] : maxb;
+    code[i] = enc_width_code(enc_bits_n(brl[i], 64));
+  }
+  maxb = wave_max_i64(maxb);
+  enc_hist(hist, code, e.cnt, lane);
+  const uint32_t w100 = enc_bits_n(maxb, 64);
+  uint32_t w95 = enc_percentile(hist, len, 0.95f);
+  __builtin_amdgcn_wave_barrier();
+  if (w100 == w95) return;  // DIRECT
+  if (w100 < w95 || mn == INT64_MIN) {
+    rec.panic = 1;  // the reference panics here (patched_base.rs:235 / :259): DIRECT
+    return;
+  }
+  uint32_t pbw = enc_fixed_bits(w100 - w95);
+  if (pbw == 64) {
+    pbw = 56;
+    w95 = 8;
+  }
+  const int64_t mask = (int64_t)(((uint64_t)1 << w95) - 1);
+  uint32_t flags = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    if ((uint32_t)i < e.cnt && brl[i] > mask) flags |= 1u << i;
+  const uint32_t np = enc_patch_indexes(idx, flags, lane);
+  uint32_t gap = 0, extra = 0;
+  if (lane < np) {
+    gap = idx[lane] - (lane ? idx[lane - 1] : 0);
+    extra = gap == 511 ? 2 : (gap > 255 ? 1 : 0);
+  }
+  const bool jumps = __ballot(extra != 0) != 0;
+  const uint32_t ne = np + (uint32_t)__builtin_popcountll(__ballot(extra == 1)) + 2 * (uint32_t)__builtin_popcountll(__ballot(extra == 2));
+  const uint32_t max_gap = jumps ? 255 : wave_max_u32(lane < np ? gap : 0);
+  const uint32_t pgw = max_gap ? 32u - (uint32_t)__builtin_clz(max_gap) : 1u;
+  const uint64_t amin = mn < 0 ? (uint64_t)0 - (uint64_t)mn : (uint64_t)mn;
+  uint32_t bb = (enc_fixed_bits(enc_bits_n((int64_t)amin, 64) + 1) + 7) / 8;
+  bb = bb ? bb : 1;
+  rec.mode = 2;
+  rec.w = (uint8_t)enc_fixed_bits(w95);
+  rec.w95 = (uint8_t)w95;
+  rec.pbw = (uint8_t)pbw;
+  rec.pgw = (uint8_t)pgw;
+  rec.ne = (uint8_t)ne;
+  rec.base = mn;
+  bytes = 4 + bb + (len * rec.w + 7) / 8 + (ne * enc_fixed_bits(pgw + pbw) + 7) / 8;
+  __builtin_amdgcn_wave_barrier();
+}
+
 extern "C" __global__ void __launch_bounds__(256) enc2_plan_kernel(const void* values, int int_bytes, int is_signed, const uint16_t* next16, const uint32_t* runs,
-                                                                   uint32_t n_runs, EncRun* recs, uint32_t* run_bytes) {
+                                                                   uint32_t n_runs, EncRun* recs, uint32_t* run_bytes, uint32_t rpw) {
   __shared__ uint32_t lds[4][96];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t* hist = lds[wave];
   uint32_t* idx = lds[wave] + 32;
   const uint32_t nbits = (uint32_t)int_bytes * 8;
-  for (uint32_t rr = 0; rr < ENC_RUNS_PER_WAVE; rr++) {
-    const uint32_t r = (blockIdx.x * 4 + wave) * ENC_RUNS_PER_WAVE + rr;
-    if (r >= n_runs) return;
-    const uint32_t start = runs[r];
-    const uint32_t e16 = next16[start];
-    const uint32_t len = e16 & 0x3ffu;
+  // (rpw runs per wavefront, 4 .. 64: many short runs -- a lane each --, or few long ones -- the wavefront one after the other)
+  const uint32_t r0 = (blockIdx.x * 4 + wave) * rpw, r = r0 + lane;
+  const bool have = lane < rpw && r < n_runs;
+  uint32_t start = 0, e16 = 0;
+  if (have) {
+    start = runs[r];
+    e16 = next16[start];
+  }
+  const uint32_t len = e16 & 0x3ffu;
+  const bool coop = have && !(e16 & 0x8000u) && len > 3;
+  if (have && !coop) {
     EncRun rec;
     rec.start = start;
     rec.len = (uint16_t)len;
@@ -407,7 +537,7 @@ extern "C" __global__ void __launch_bounds__(256) enc2_plan_kernel(const void* v
     rec.panic = 0;
     rec.base = 0;
     uint32_t bytes;
-    if (e16 & 0x8000u) {  // repeats: SHORT_REPEAT up to 10, a DELTA of step 0 beyond (rle_v2/mod.rs:303-337, :361-384)
+    if (e16 & 0x8000u) {
       const int64_t z = enc_zigzag_n(enc_ld(values, start, int_bytes), nbits, is_signed);
       if (len <= 10) {
         uint32_t b = (enc_bits_n(z, nbits) + 7) / 8;
@@ -420,276 +550,189 @@ extern "C" __global__ void __launch_bounds__(256) enc2_plan_kernel(const void* v
         rec.w = 0;
         bytes = 2 + enc_varint_len(z, nbits) + 1;
       }
-    } else {
-      const EncVals e = enc_load_run(values, int_bytes, start, len, lane);
-      int64_t zz[8];
+    } else {  // up to three literals: DIRECT at the width of the widest
       uint32_t zbits = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        zz[i] = enc_zigzag_n(e.v[i], nbits, is_signed);
-        if ((uint32_t)i < e.cnt) {
-          const uint32_t b = enc_bits_n(zz[i], nbits);
-          zbits = b > zbits ? b : zbits;
-        }
+      for (uint32_t i = 0; i < len; i++) {
+        const uint32_t b = enc_bits_n(enc_zigzag_n(enc_ld(values, (uint64_t)start + i, int_bytes), nbits, is_signed), nbits);
+        zbits = b > zbits ? b : zbits;
       }
-      zbits = wave_max_u32(zbits);
-      const uint32_t direct_w = enc_aligned_bits(zbits);
-      const uint32_t direct_bytes = 2 + (len * direct_w + 7) / 8;
+      const uint32_t w = enc_aligned_bits(zbits);
       rec.mode = 1;
-      rec.w = (uint8_t)direct_w;
-      bytes = direct_bytes;
-      if (len > 3) {
-        // delta_encoding_check (rle_v2/mod.rs:186-239)
-        const int64_t v0 = (int64_t)__shfl((long long)e.v[0], 0), v1 = (int64_t)__shfl((long long)e.v[1], 0);
-        const int64_t first_delta = enc_sat_sub(v1, v0);
-        const int64_t below = (int64_t)__shfl_up((long long)e.v[7], 1);
-        int64_t mn = INT64_MAX, mx = INT64_MIN, maxd = 0;
-        bool inc = true, dec = true, fx = true;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          if ((uint32_t)i < e.cnt) {
-            mn = e.v[i] < mn ? e.v[i] : mn;
-            mx = e.v[i] > mx ? e.v[i] : mx;
-            const uint32_t gi = lane * 8 + i;
-            if (gi >= 2) {
-              const int64_t cur = enc_sat_sub(e.v[i], i ? e.v[i ? i - 1 : 0] : below);
-              inc = inc && cur >= 0;
-              dec = dec && cur <= 0;
-              fx = fx && cur == first_delta;
-              const int64_t a = enc_sat_abs(cur);
-              maxd = a > maxd ? a : maxd;
-            }
-          }
-        }
-        mn = wave_min_i64(mn);
-        mx = wave_max_i64(mx);
-        maxd = wave_max_i64(maxd);
-        const bool is_inc = first_delta > 0 && !__ballot(!inc), is_dec = first_delta < 0 && !__ballot(!dec), is_fixed = !__ballot(!fx);
-        int64_t range;
-        bool ovf = __builtin_sub_overflow(mx, mn, &range);
-        if (!ovf && nbits < 64) ovf = range >= ((int64_t)1 << (nbits - 1));
-        const int64_t zbase = enc_zigzag_n(v0, nbits, is_signed);
-        const int64_t zfirst = enc_zigzag_n(first_delta, 64, 1);
-        if (ovf) {
-          // DIRECT
-        } else if (is_fixed) {
-          rec.mode = 3;
-          rec.w = 0;
-          bytes = 2 + enc_varint_len(zbase, nbits) + enc_varint_len(zfirst, 64);
-        } else if (first_delta != 0 && (is_inc || is_dec)) {
-          uint32_t w = enc_aligned_bits(enc_bits_n(maxd, 64));
-          w = w == 1 ? 2 : w;
-          rec.mode = 4;
-          rec.w = (uint8_t)w;
-          bytes = 2 + enc_varint_len(zbase, nbits) + enc_varint_len(zfirst, 64) + ((len - 2) * w + 7) / 8;
-        } else if (mn != INT64_MIN && (mn < 0 ? -mn : mn) >= ((int64_t)1 << 56)) {
-          // DIRECT
-        } else {
-          uint32_t code[8];
-#pragma unroll
-          for (int i = 0; i < 8; i++) code[i] = enc_width_code(enc_bits_n(zz[i], nbits));
-          enc_hist(hist, code, e.cnt, lane);
-          const uint32_t z90 = enc_percentile(hist, len, 0.90f), z100 = enc_percentile(hist, len, 1.00f);
-          __builtin_amdgcn_wave_barrier();
-          if (z100 > z90 + 1) {
-            int64_t brl[8], maxb = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-              brl[i] = (uint32_t)i < e.cnt ? e.v[i] - mn : 0;
-              maxb = brl[i] > maxb ? brl[i] : maxb;
-              code[i] = enc_width_code(enc_bits_n(brl[i], 64));
-            }
-            maxb = wave_max_i64(maxb);
-            enc_hist(hist, code, e.cnt, lane);
-            const uint32_t w100 = enc_bits_n(maxb, 64);
-            uint32_t w95 = enc_percentile(hist, len, 0.95f);
-            __builtin_amdgcn_wave_barrier();
-            if (w100 != w95) {
-              if (w100 < w95 || mn == INT64_MIN) {
-                rec.panic = 1;  // the reference panics here (patched_base.rs:235 / :259): DIRECT
-              } else {
-                uint32_t pbw = enc_fixed_bits(w100 - w95);
-                if (pbw == 64) {
-                  pbw = 56;
-                  w95 = 8;
-                }
-                const int64_t mask = (int64_t)(((uint64_t)1 << w95) - 1);
-                uint32_t flags = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                  if ((uint32_t)i < e.cnt && brl[i] > mask) flags |= 1u << i;
-                const uint32_t np = enc_patch_indexes(idx, flags, lane);
-                uint32_t gap = 0, extra = 0;
-                if (lane < np) {
-                  gap = idx[lane] - (lane ? idx[lane - 1] : 0);
-                  extra = gap == 511 ? 2 : (gap > 255 ? 1 : 0);
-                }
-                const bool jumps = __ballot(extra != 0) != 0;
-                uint32_t ne = np + (uint32_t)__builtin_popcountll(__ballot(extra == 1)) + 2 * (uint32_t)__builtin_popcountll(__ballot(extra == 2));
-                const uint32_t max_gap = jumps ? 255 : wave_max_u32(lane < np ? gap : 0);
-                const uint32_t pgw = max_gap ? 32u - (uint32_t)__builtin_clz(max_gap) : 1u;
-                const uint64_t amin = mn < 0 ? (uint64_t)0 - (uint64_t)mn : (uint64_t)mn;
-                uint32_t bb = (enc_fixed_bits(enc_bits_n((int64_t)amin, 64) + 1) + 7) / 8;
-                bb = bb ? bb : 1;
-                rec.mode = 2;
-                rec.w = (uint8_t)enc_fixed_bits(w95);
-                rec.w95 = (uint8_t)w95;
-                rec.pbw = (uint8_t)pbw;
-                rec.pgw = (uint8_t)pgw;
-                rec.ne = (uint8_t)ne;
-                rec.base = mn;
-                bytes = 4 + bb + (len * rec.w + 7) / 8 + (ne * enc_fixed_bits(pgw + pbw) + 7) / 8;
-                __builtin_amdgcn_wave_barrier();
-              }
-            }
-          }
-        }
-      }
+      rec.w = (uint8_t)w;
+      bytes = 2 + (len * w + 7) / 8;
     }
+    recs[r] = rec;
+    run_bytes[r] = bytes;
+  }
+  unsigned long long m = __ballot(coop);
+  while (m) {
+    const int src = __builtin_ctzll(m);
+    m &= m - 1;
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)start, src), l0 = (uint32_t)__builtin_amdgcn_readlane((int)len, src);
+    EncRun rec;
+    rec.start = s0;
+    rec.len = (uint16_t)l0;
+    rec.pbw = rec.pgw = rec.ne = rec.w95 = 0;
+    rec.panic = 0;
+    rec.base = 0;
+    uint32_t bytes = 0;
+    enc2_plan_coop(values, int_bytes, nbits, is_signed, s0, l0, lane, hist, idx, rec, bytes);
     if (lane == 0) {
-      recs[r] = rec;
-      run_bytes[r] = bytes;
+      recs[r0 + src] = rec;
+      run_bytes[r0 + src] = bytes;
     }
   }
 }
 
 // 4b. the runs written: write_short_repeat (short_repeat.rs:65-81), write_direct (direct.rs:69-95), write_fixed_delta /
-// write_varying_delta (delta.rs:118-182), write_patched_base (patched_base.rs:228-284)
+// write_varying_delta (delta.rs:118-182), write_patched_base (patched_base.rs:228-284).  As in the plan: repeats, fixed steps and
+// up to three literals by their lane, the rest by the wavefront.
+__device__ __forceinline__ void enc2_emit_coop(const void* values, int int_bytes, uint32_t nbits, int is_signed, const EncRun& rec, uint8_t* p, uint32_t lane,
+                                               uint32_t* idx, uint64_t* ent) {
+  const uint32_t len = rec.len, w = rec.w;
+  if (rec.mode == 1) {
+    if (lane == 0) {
+      p[0] = (uint8_t)(0x40u | (enc_width_code(w) << 1) | ((len - 1) >> 8));
+      p[1] = (uint8_t)((len - 1) & 0xff);
+    }
+    const EncVals e = enc_load_run(values, int_bytes, rec.start, len, lane);
+    uint64_t u[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) u[i] = (uint64_t)enc_zigzag_n(e.v[i], nbits, is_signed);
+    if (e.cnt) enc_pack8(p + 2 + (uint64_t)lane * w, u, e.cnt, w);
+    return;
+  }
+  if (rec.mode == 4) {
+    const int64_t v0 = enc_ld(values, rec.start, int_bytes), v1 = enc_ld(values, rec.start + 1, int_bytes);
+    const int64_t zbase = enc_zigzag_n(v0, nbits, is_signed), zfirst = enc_zigzag_n(enc_sat_sub(v1, v0), 64, 1);
+    const uint32_t head = 2 + enc_varint_len(zbase, nbits) + enc_varint_len(zfirst, 64);
+    if (lane == 0) {
+      p[0] = (uint8_t)(0xc0u | (enc_width_code(w) << 1) | ((len - 1) >> 8));
+      p[1] = (uint8_t)((len - 1) & 0xff);
+      uint32_t k = 2;
+      k += enc_put_varint(p + k, zbase, nbits);
+      k += enc_put_varint(p + k, zfirst, 64);
+    }
+    // steps 2 .. len - 1: lane l packs |v[j + 2] - v[j + 1]| for j = 8 l .. 8 l + 7
+    const uint32_t n_adj = len - 2, lo = lane * 8;
+    const uint32_t cnt = lo < n_adj ? (n_adj - lo < 8 ? n_adj - lo : 8) : 0;
+    if (cnt) {
+      uint64_t u[8];
+      int64_t prev = enc_ld(values, (uint64_t)rec.start + lo + 1, int_bytes);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        u[i] = 0;
+        if ((uint32_t)i < cnt) {
+          const int64_t cur = enc_ld(values, (uint64_t)rec.start + lo + 2 + i, int_bytes);
+          u[i] = (uint64_t)enc_sat_abs(enc_sat_sub(cur, prev));
+          prev = cur;
+        }
+      }
+      enc_pack8(p + head + (uint64_t)lane * w, u, cnt, w);
+    }
+    return;
+  }
+  // PATCHED_BASE
+  const int64_t mn = rec.base;
+  const uint32_t w95 = rec.w95, pbw = rec.pbw, pgw = rec.pgw;
+  const uint64_t amin = mn < 0 ? (uint64_t)0 - (uint64_t)mn : (uint64_t)mn;
+  uint32_t bb = (enc_fixed_bits(enc_bits_n((int64_t)amin, 64) + 1) + 7) / 8;
+  bb = bb ? bb : 1;
+  if (lane == 0) {
+    p[0] = (uint8_t)(0x80u | (enc_width_code(w95) << 1) | ((len - 1) >> 8));
+    p[1] = (uint8_t)((len - 1) & 0xff);
+    p[2] = (uint8_t)(((bb - 1) << 5) | enc_width_code(pbw));
+    p[3] = (uint8_t)(((pgw - 1) << 5) | rec.ne);
+    const uint64_t msb = amin | ((uint64_t)(mn < 0) << (bb * 8 - 1));
+    for (uint32_t k = 0; k < bb; k++) p[4 + k] = (uint8_t)(msb >> (8 * (bb - 1 - k)));
+  }
+  const EncVals e = enc_load_run(values, int_bytes, rec.start, len, lane);
+  const int64_t mask = (int64_t)(((uint64_t)1 << w95) - 1);
+  uint64_t u[8];
+  uint32_t flags = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int64_t b = (uint32_t)i < e.cnt ? e.v[i] - mn : 0;
+    if (b > mask) flags |= 1u << i;
+    u[i] = (uint64_t)(b & mask);
+  }
+  if (e.cnt) enc_pack8(p + 4 + bb + (uint64_t)lane * w, u, e.cnt, w);
+  const uint32_t np = enc_patch_indexes(idx, flags, lane);
+  uint32_t gap = 0, extra = 0;
+  uint64_t patch_bits = 0;
+  if (lane < np) {
+    const uint32_t at = idx[lane];
+    gap = at - (lane ? idx[lane - 1] : 0);
+    extra = gap == 511 ? 2 : (gap > 255 ? 1 : 0);
+    gap = gap == 511 ? 1 : (gap > 255 ? gap - 255 : gap);
+    patch_bits = (uint64_t)(enc_ld(values, (uint64_t)rec.start + at, int_bytes) - mn) >> w95;
+  }
+  uint32_t inc = extra + (lane < np ? 1u : 0u);
+  const uint32_t mine = inc;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)inc, o);
+    if (lane >= (uint32_t)o) inc += y;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < np) {
+    uint32_t at = inc - mine;
+    const uint64_t jump = (uint64_t)255 << pbw;
+    for (uint32_t k = 0; k < extra; k++) ent[at++] = jump;
+    ent[at] = patch_bits | ((uint64_t)gap << pbw);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t ne = rec.ne, pw = enc_fixed_bits(pgw + pbw), lo = lane * 8;
+  const uint32_t cnt = lo < ne ? (ne - lo < 8 ? ne - lo : 8) : 0;
+  if (cnt) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) u[i] = (uint32_t)i < cnt ? ent[lo + i] : 0;
+    enc_pack8(p + 4 + bb + (len * w + 7) / 8 + (uint64_t)lane * pw, u, cnt, pw);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 extern "C" __global__ void __launch_bounds__(256) enc2_emit_kernel(const void* values, int int_bytes, int is_signed, const EncRun* recs, const uint64_t* offsets,
-                                                                   uint32_t n_runs, uint8_t* out) {
+                                                                   uint32_t n_runs, uint8_t* out, uint32_t rpw) {
   __shared__ uint32_t lds32[4][64];
   __shared__ uint64_t lds64[4][32];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint32_t* idx = lds32[wave];
-  uint64_t* ent = lds64[wave];
   const uint32_t nbits = (uint32_t)int_bytes * 8;
-  for (uint32_t rr = 0; rr < ENC_RUNS_PER_WAVE; rr++) {
-    const uint32_t r = (blockIdx.x * 4 + wave) * ENC_RUNS_PER_WAVE + rr;
-    if (r >= n_runs) return;
-    const EncRun rec = recs[r];
+  const uint32_t r0 = (blockIdx.x * 4 + wave) * rpw, r = r0 + lane;
+  EncRun rec;
+  rec.mode = 0xff;
+  rec.len = 0;
+  bool coop = false;
+  if (lane < rpw && r < n_runs) {
+    rec = recs[r];
     const uint32_t len = rec.len;
     uint8_t* p = out + offsets[r];
     if (rec.mode == 0) {
-      if (lane == 0) {
-        const int64_t z = enc_zigzag_n(enc_ld(values, rec.start, int_bytes), nbits, is_signed);
-        p[0] = (uint8_t)(((rec.w - 1u) << 3) | (len - 3u));
-        for (uint32_t k = 0; k < rec.w; k++) p[1 + k] = (uint8_t)((uint64_t)z >> (8 * (rec.w - 1 - k)));
-      }
-      continue;
-    }
-    if (rec.mode == 3) {
-      if (lane == 0) {
-        const int64_t v0 = enc_ld(values, rec.start, int_bytes), v1 = enc_ld(values, rec.start + 1, int_bytes);
-        p[0] = (uint8_t)(0xc0u | ((len - 1) >> 8));
-        p[1] = (uint8_t)((len - 1) & 0xff);
-        uint32_t k = 2;
-        k += enc_put_varint(p + k, enc_zigzag_n(v0, nbits, is_signed), nbits);
-        k += enc_put_varint(p + k, enc_zigzag_n(enc_sat_sub(v1, v0), 64, 1), 64);
-      }
-      continue;
-    }
-    const uint32_t w = rec.w;
-    if (rec.mode == 1) {
-      if (lane == 0) {
-        p[0] = (uint8_t)(0x40u | (enc_width_code(w) << 1) | ((len - 1) >> 8));
-        p[1] = (uint8_t)((len - 1) & 0xff);
-      }
-      const EncVals e = enc_load_run(values, int_bytes, rec.start, len, lane);
-      uint64_t u[8];
-#pragma unroll
-      for (int i = 0; i < 8; i++) u[i] = (uint64_t)enc_zigzag_n(e.v[i], nbits, is_signed);
-      if (e.cnt) enc_pack8(p + 2 + (uint64_t)lane * w, u, e.cnt, w);
-      continue;
-    }
-    if (rec.mode == 4) {
+      const int64_t z = enc_zigzag_n(enc_ld(values, rec.start, int_bytes), nbits, is_signed);
+      p[0] = (uint8_t)(((rec.w - 1u) << 3) | (len - 3u));
+      for (uint32_t k = 0; k < rec.w; k++) p[1 + k] = (uint8_t)((uint64_t)z >> (8 * (rec.w - 1 - k)));
+    } else if (rec.mode == 3) {
       const int64_t v0 = enc_ld(values, rec.start, int_bytes), v1 = enc_ld(values, rec.start + 1, int_bytes);
-      const int64_t zbase = enc_zigzag_n(v0, nbits, is_signed), zfirst = enc_zigzag_n(enc_sat_sub(v1, v0), 64, 1);
-      const uint32_t head = 2 + enc_varint_len(zbase, nbits) + enc_varint_len(zfirst, 64);
-      if (lane == 0) {
-        p[0] = (uint8_t)(0xc0u | (enc_width_code(w) << 1) | ((len - 1) >> 8));
-        p[1] = (uint8_t)((len - 1) & 0xff);
-        uint32_t k = 2;
-        k += enc_put_varint(p + k, zbase, nbits);
-        k += enc_put_varint(p + k, zfirst, 64);
-      }
-      // steps 2 .. len - 1: lane l packs |v[j + 2] - v[j + 1]| for j = 8 l .. 8 l + 7
-      const uint32_t n_adj = len - 2, lo = lane * 8;
-      const uint32_t cnt = lo < n_adj ? (n_adj - lo < 8 ? n_adj - lo : 8) : 0;
-      if (cnt) {
-        uint64_t u[8];
-        int64_t prev = enc_ld(values, (uint64_t)rec.start + lo + 1, int_bytes);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          u[i] = 0;
-          if ((uint32_t)i < cnt) {
-            const int64_t cur = enc_ld(values, (uint64_t)rec.start + lo + 2 + i, int_bytes);
-            u[i] = (uint64_t)enc_sat_abs(enc_sat_sub(cur, prev));
-            prev = cur;
-          }
-        }
-        enc_pack8(p + head + (uint64_t)lane * w, u, cnt, w);
-      }
-      continue;
+      p[0] = (uint8_t)(0xc0u | ((len - 1) >> 8));
+      p[1] = (uint8_t)((len - 1) & 0xff);
+      uint32_t k = 2;
+      k += enc_put_varint(p + k, enc_zigzag_n(v0, nbits, is_signed), nbits);
+      k += enc_put_varint(p + k, enc_zigzag_n(enc_sat_sub(v1, v0), 64, 1), 64);
+    } else if (rec.mode == 1 && len <= 3) {
+      p[0] = (uint8_t)(0x40u | (enc_width_code(rec.w) << 1));
+      p[1] = (uint8_t)(len - 1);
+      uint64_t u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t i = 0; i < len; i++) u[i] = (uint64_t)enc_zigzag_n(enc_ld(values, (uint64_t)rec.start + i, int_bytes), nbits, is_signed);
+      enc_pack8(p + 2, u, len, rec.w);
+    } else {
+      coop = true;
     }
-    // PATCHED_BASE
-    {
-      const int64_t mn = rec.base;
-      const uint32_t w95 = rec.w95, pbw = rec.pbw, pgw = rec.pgw;
-      const uint64_t amin = mn < 0 ? (uint64_t)0 - (uint64_t)mn : (uint64_t)mn;
-      uint32_t bb = (enc_fixed_bits(enc_bits_n((int64_t)amin, 64) + 1) + 7) / 8;
-      bb = bb ? bb : 1;
-      if (lane == 0) {
-        p[0] = (uint8_t)(0x80u | (enc_width_code(w95) << 1) | ((len - 1) >> 8));
-        p[1] = (uint8_t)((len - 1) & 0xff);
-        p[2] = (uint8_t)(((bb - 1) << 5) | enc_width_code(pbw));
-        p[3] = (uint8_t)(((pgw - 1) << 5) | rec.ne);
-        const uint64_t msb = amin | ((uint64_t)(mn < 0) << (bb * 8 - 1));
-        for (uint32_t k = 0; k < bb; k++) p[4 + k] = (uint8_t)(msb >> (8 * (bb - 1 - k)));
-      }
-      const EncVals e = enc_load_run(values, int_bytes, rec.start, len, lane);
-      const int64_t mask = (int64_t)(((uint64_t)1 << w95) - 1);
-      uint64_t u[8];
-      uint32_t flags = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const int64_t b = (uint32_t)i < e.cnt ? e.v[i] - mn : 0;
-        if (b > mask) flags |= 1u << i;
-        u[i] = (uint64_t)(b & mask);
-      }
-      if (e.cnt) enc_pack8(p + 4 + bb + (uint64_t)lane * w, u, e.cnt, w);
-      const uint32_t np = enc_patch_indexes(idx, flags, lane);
-      uint32_t gap = 0, extra = 0;
-      uint64_t patch_bits = 0;
-      if (lane < np) {
-        const uint32_t at = idx[lane];
-        gap = at - (lane ? idx[lane - 1] : 0);
-        extra = gap == 511 ? 2 : (gap > 255 ? 1 : 0);
-        gap = gap == 511 ? 1 : (gap > 255 ? gap - 255 : gap);
-        patch_bits = (uint64_t)(enc_ld(values, (uint64_t)rec.start + at, int_bytes) - mn) >> w95;
-      }
-      uint32_t inc = extra + (lane < np ? 1u : 0u);
-      const uint32_t mine = inc;
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)inc, o);
-        if (lane >= (uint32_t)o) inc += y;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < np) {
-        uint32_t at = inc - mine;
-        const uint64_t jump = (uint64_t)255 << pbw;
-        for (uint32_t k = 0; k < extra; k++) ent[at++] = jump;
-        ent[at] = patch_bits | ((uint64_t)gap << pbw);
-      }
-      __builtin_amdgcn_wave_barrier();
-      const uint32_t ne = rec.ne, pw = enc_fixed_bits(pgw + pbw), lo = lane * 8;
-      const uint32_t cnt = lo < ne ? (ne - lo < 8 ? ne - lo : 8) : 0;
-      if (cnt) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) u[i] = (uint32_t)i < cnt ? ent[lo + i] : 0;
-        enc_pack8(p + 4 + bb + (len * w + 7) / 8 + (uint64_t)lane * pw, u, cnt, pw);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
+  }
+  unsigned long long m = __ballot(coop);
+  while (m) {
+    const int src = __builtin_ctzll(m);
+    m &= m - 1;
+    const EncRun rc = recs[r0 + src];
+    enc2_emit_coop(values, int_bytes, nbits, is_signed, rc, out + offsets[r0 + src], lane, lds32[wave], lds64[wave]);
   }
 }
 

@@ -135,7 +135,7 @@ struct StagedStream {
   uint64_t len;
   std::vector<ChunkInfo> chunks;  // only for compressed stripes
   std::vector<ZChunkParse> zchunks;  // Zstandard: frame / block headers of every compressed chunk
-  uint32_t skip_bytes = 0, skip_values = 0;  // entry point (orcgpu_stream): where in the plain bytes the decoder starts, values it drops
+  uint32_t skip_bytes = 0, skip_values = 0, skip_bits = 0;  // entry point (orcgpu_stream): where in the plain bytes the decoder starts, values it drops, bits of a bit stream's first byte that come before
   std::vector<std::pair<uint32_t, uint32_t>> hints;  // verified run starts (orcgpu_stream::entries): (chunk index or ~0, byte in its plain bytes), the stream's start first
   bool framing_error = false;     // truncated chunk header / payload (compression.rs:253-261 panics)
   uint64_t framed_len = 0;        // bytes covered by well-formed chunks
@@ -634,6 +634,7 @@ struct PlainStream {
   uint32_t len_idx = 0;          // scalar holding the actual plain length
   uint32_t err_idx = 0;          // scalar holding a codec error flag (compressed streams)
   uint32_t skip_values = 0;      // entered at a row group: values of the first run that come before the column's (orcgpu_stream)
+  uint32_t skip_bits = 0;        // ... and, of a bit stream, bits of its first byte
   const StagedStream* src = nullptr;  // (for its verified run starts)
   uint32_t chunk0 = 0;           // compressed: index of the stream's first chunk in the call's chunk table
   bool exists = false;
@@ -657,6 +658,8 @@ struct ColPlan {
   int parent_plan = -1;       // index in Plan::cols of the Struct this column is a field of (only when that one has validity)
   int depth = 0;              // Structs above it
   uint32_t ceil8_idx = 0;     // Struct: scalar holding ceil(non-null rows / 8), the length of its fields' PRESENT streams
+  uint32_t child_bits = 0;    // ... entered at a row group in mid-byte: the bits of their first byte that belong to the rows before
+  bool child_bits_set = false;
   // Union (union.rs:69-136): behind the Union's own plan follow its ARMS, one per child: plans without a column of their own
   // (col = -1) that stand where a Struct stands above a field -- valid where the Union is present and its tag names the arm
   int arm0 = -1, n_arms = 0;  // the Union: its first arm in Plan::cols
@@ -884,14 +887,14 @@ int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_sta
   for (uint32_t i = 0; i < d->n_streams; i++) {
     // entry points (orcgpu_stream): a run holds at most 512 values, a chunk at most block_size bytes; dictionaries come whole
     const orcgpu_stream& in = d->streams[i];
-    if (!in.skip_bytes && !in.skip_values) continue;
+    if (!in.skip_bytes && !in.skip_values && !in.skip_bits) continue;
     bool dict_stream = in.kind == ORCGPU_S_DICTIONARY_DATA;
     for (uint32_t k = 0; k < d->n_columns; k++)
       if (d->columns[k].column_id == in.column_id && in.kind == ORCGPU_S_LENGTH && is_string_type(d->columns[k].orc_type) &&
           d->columns[k].orc_type != ORCGPU_T_BINARY &&
           (d->columns[k].encoding == ORCGPU_ENC_DICTIONARY || d->columns[k].encoding == ORCGPU_ENC_DICTIONARY_V2))
         dict_stream = true;
-    if (in.skip_values > 512 || in.skip_bytes > s->desc.block_size || dict_stream) {
+    if (in.skip_values > 512 || in.skip_bytes > s->desc.block_size || dict_stream || in.skip_bits > 7) {
       set_err(ctx, "stream (column %u, kind %d): entry point {%u bytes, %u values} is not one a ROW_INDEX position can name", in.column_id, in.kind,
               in.skip_bytes, in.skip_values);
       delete s;
@@ -910,6 +913,7 @@ int orcgpu_stage_stripe(orcgpu_ctx* ctx, const orcgpu_stripe_desc* d, orcgpu_sta
     st.len = in.len;
     st.skip_bytes = in.skip_bytes;
     st.skip_values = in.skip_values;
+    st.skip_bits = in.skip_bits;
     st.off = b.take(in.len + ORC_PAD);
     s->stream_bytes += in.len;
     if (d->compression != ORCGPU_COMP_NONE) scan_chunks(in.ptr, in.len, d->compression, s->desc.block_size, st);
@@ -1084,6 +1088,7 @@ PlainStream plan_stream(Plan& P, orcgpu_staged* s, uint32_t col, int kind) {
   }
   ps.exists = true;
   ps.skip_values = st->skip_values;
+  ps.skip_bits = st->skip_bits;
   ps.src = st;
   if (s->desc.compression == ORCGPU_COMP_NONE) {
     const uint64_t skip = std::min<uint64_t>(st->skip_bytes, st->len);

@@ -186,9 +186,9 @@ def test_one_percent_of_the_row_groups(tmp_path):
 
 
 def test_structs_and_unusable_indexes(tmp_path):
-    """Fields of Structs take their entry points like root columns; what the index cannot express -- a bit stream entered in
-    mid-byte (Boolean values behind nulls, the PRESENT stream of a field of a Struct with nulls) -- is decoded whole, with the
-    same batches (a file without indexes: test_reference_fixtures_with_and_without_index)."""
+    """Fields of Structs take their entry points like root columns; bit streams entered in mid-byte (Boolean values behind nulls,
+    the PRESENT stream of a field of a Struct with nulls: orcgpu_stream::skip_bits, round 5) are pruned like the others (a file
+    without indexes: test_reference_fixtures_with_and_without_index)."""
     n = 30_000
     rng = np.random.default_rng(11)
     inner = pa.StructArray.from_arrays([pa.array(rng.integers(0, 1 << 30, n)), pa.array(["s%d" % (i % 97) for i in range(n)])], names=["a", "b"])
@@ -199,14 +199,24 @@ def test_structs_and_unusable_indexes(tmp_path):
     # Boolean values with nulls: the DATA bit stream is entered in mid-byte at most row groups
     flags = pa.table({"id": pa.array(np.arange(n, dtype=np.int64)), "f": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.37)})
     path = write(tmp_path, flags, "b.orc", compression="uncompressed", row_index_stride=1000)
-    check(flags, path, sel, expect_pruned=False)
-    # ... the other column alone is pruned
+    check(flags, path, sel)
+    check(flags, path, [S(12_345), K(3), S(9_000), K(2_000), S(n - 12_345 - 3 - 9_000 - 2_000)], batch_size=333)
     check(flags, path, sel, names=["id"])
     # a Struct with nulls: its fields' PRESENT streams count the Struct's non-null rows
     st = pa.StructArray.from_arrays([pa.array(rng.integers(0, 99, n), mask=rng.random(n) < 0.2)], names=["a"], mask=pa.array(rng.random(n) < 0.3))
     nul = pa.table({"id": pa.array(np.arange(n, dtype=np.int64)), "st": st})
     path = write(tmp_path, nul, "n.orc", compression="snappy", row_index_stride=1000)
-    check(nul, path, sel, expect_pruned=False)
+    check(nul, path, sel)
+    # ... two levels of Structs with nulls, a Boolean field with nulls inside
+    inner2 = pa.StructArray.from_arrays([pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.4), pa.array(rng.integers(0, 9, n), mask=rng.random(n) < 0.1)],
+                                        names=["f", "v"], mask=pa.array(rng.random(n) < 0.25))
+    outer = pa.StructArray.from_arrays([inner2, pa.array(["s%d" % (i % 13) for i in range(n)], mask=rng.random(n) < 0.3)], names=["in", "s"],
+                                       mask=pa.array(rng.random(n) < 0.2))
+    deep = pa.table({"id": pa.array(np.arange(n, dtype=np.int64)), "o": outer})
+    for comp in ("uncompressed", "zstd"):
+        path = write(tmp_path, deep, "d_%s.orc" % comp, compression=comp, compression_block_size=65536, row_index_stride=1000)
+        check(deep, path, sel)
+        check(deep, path, [S(999), K(2), S(20_000), K(1500), S(3), K(1), S(n - 999 - 2 - 20_000 - 1500 - 3 - 1)], batch_size=512)
 
 
 def test_lists_and_maps_are_pruned_like_flat_columns(tmp_path):
@@ -231,9 +241,9 @@ def test_lists_and_maps_are_pruned_like_flat_columns(tmp_path):
     for comp, block in (("uncompressed", 65536), ("zstd", 65536), ("snappy", 65536)):
         path = write(tmp_path, table, "l_%s.orc" % comp, compression=comp, compression_block_size=block, row_index_stride=1000, stripe_size=64 << 20)
         assert len(stripe_rows(path)) == 1
-        # elements with nulls (`ints`, the values of `maps`): their PRESENT streams are entered in mid-byte at most row groups -- such a
-        # projection is decoded whole, with the same batches
-        check(table, path, sel, batch_size=700, expect_pruned=False)
+        # (elements with nulls -- `ints`, the values of `maps` --: their PRESENT streams are entered in mid-byte at most row groups)
+        g_read, g_total = check(table, path, sel, batch_size=700)
+        assert g_read < g_total == 60, (g_read, g_total)
         g_read, g_total = check(table, path, sel, batch_size=700, names=["id", "strs", "nested"])
         assert g_read < g_total == 60, (g_read, g_total)
         g_read, g_total = check(table, path, [S(59_990), K(10)], names=["nested"])
