@@ -290,8 +290,95 @@ __device__ __forceinline__ void hb_skip(HBits& h, int nb) {
   }
 }
 
+// The same cursor with its bytes in LDS (zstd_literals_kernel).  With the window refilled from memory where a lane needs it, SOME
+// lane of the wavefront issues a load in nearly every trip of the symbol loop, and the wait in front of the next use of a
+// refilled word -- one counter for the whole wavefront -- then waits for that load: a memory round trip per symbol, ~1-2 us
+// (1 650 symbol steps per lane took 1.7 ms).  Here every lane copies ZL_CHUNK bytes of its segment to LDS at once -- all lanes in the
+// same trip of an outer loop, ZL_CHUNK / 16 loads in flight per lane -- and the symbol loop touches LDS only; a lane whose chunk is
+// used up leaves the inner loop and waits for the others, who are at most some symbols behind (same code lengths on average).
+#ifndef ZL_CHUNK
+#define ZL_CHUNK 64
+#endif
+struct HBitsL {
+  const uint8_t* p;
+  uint8_t* cb;       // this wavefront's chunk buffer: 64 x ZL_CHUNK bytes, piece-interleaved (piece j of lane l at (j * 64 + l) * 16)
+  uint64_t lo, hi1;  // as HBits
+  uint64_t pf[ZL_CHUNK / 8];  // the chunk below the one in LDS, on its way from memory while that one is decoded
+  uint32_t idx;      // words of the chunk taken so far (from its top); ZL_CHUNK / 8: used up
+  int e;             // the chunk in LDS: bytes [e - ZL_CHUNK, e) of the stream; -1: none (behind a seek)
+  int wb64;
+  int pos;
+};
+__device__ __forceinline__ void hb_seek(HBitsL& h, int pos) {
+  h.pos = pos;
+  h.wb64 = (pos & ~7) - 56;
+  h.idx = ZL_CHUNK / 8;  // (nothing loaded: the refill in front of the loop does)
+  h.e = -1;
+}
+__device__ __forceinline__ uint64_t hbl_word(const HBitsL& h, uint32_t idx, uint32_t lane) {  // word `idx` of the chunk, counted from its top
+  const uint32_t o = ZL_CHUNK - 8 * (idx + 1);
+  return *reinterpret_cast<const uint64_t*>(h.cb + (((o >> 4) * 64 + lane) << 4) + (o & 8));
+}
+// bytes [e - ZL_CHUNK, e) of the stream into pf (bytes before the stream read as zero)
+__device__ __forceinline__ void hbl_load(HBitsL& h, int e) {
+#pragma unroll
+  for (int j = 0; j < ZL_CHUNK / 16; j++) {
+    const int bo = e - ZL_CHUNK + 16 * j;
+    uint64_t v[2] = {0, 0};
+    if (bo >= 0) {
+      __builtin_memcpy(v, h.p + bo, 16);
+    } else if (bo > -16) {
+      v[0] = zl_word(h.p, 8 * bo);
+      v[1] = zl_word(h.p, 8 * bo + 64);
+    }
+    h.pf[2 * j] = v[0];
+    h.pf[2 * j + 1] = v[1];
+  }
+}
+// The next chunk: the window's two words are its top (a chunk used up leaves the window 16 bytes above its bottom: the chunks
+// follow each other at a fixed distance, ZL_CHUNK - 16 bytes, so the one after is requested at once and has a whole chunk's
+// decoding to arrive in).  Behind a seek the first chunk is waited for.
+__device__ __forceinline__ void hb_refill(HBitsL& h, bool need, uint32_t lane) {
+  if (need) {
+    if (h.e < 0) {
+      h.e = (h.wb64 + 64) >> 3;
+      hbl_load(h, h.e);
+    } else {
+      h.e -= ZL_CHUNK - 16;
+    }
+#pragma unroll
+    for (int j = 0; j < ZL_CHUNK / 16; j++) {
+      const uint64_t v[2] = {h.pf[2 * j], h.pf[2 * j + 1]};
+      __builtin_memcpy(h.cb + ((j * 64 + lane) << 4), v, 16);
+    }
+    hbl_load(h, h.e - (ZL_CHUNK - 16));
+    h.hi1 = hbl_word(h, 0, lane) << 1;
+    h.lo = hbl_word(h, 1, lane);
+    h.idx = 2;
+  }
+}
+__device__ __forceinline__ bool hb_ready(const HBitsL& h) { return h.idx < ZL_CHUNK / 8; }
+__device__ __forceinline__ uint32_t hb_peek32(const HBitsL& h) {
+  const uint32_t s = (uint32_t)(h.pos - h.wb64);
+  return (uint32_t)(((h.lo >> s) | (h.hi1 << (63u - s))) >> 32);
+}
+__device__ __forceinline__ void hb_skip(HBitsL& h, int nb, uint32_t lane) {
+  h.pos -= nb;
+  if (h.pos < h.wb64) {
+    h.hi1 = h.lo << 1;
+    h.lo = hbl_word(h, h.idx, lane);
+    h.wb64 -= 64;
+    h.idx++;
+  }
+}
+// (the cursor that reads memory: always ready, nothing to refill)
+__device__ __forceinline__ void hb_refill(HBits&, bool, uint32_t) {}
+__device__ __forceinline__ bool hb_ready(const HBits&) { return true; }
+__device__ __forceinline__ void hb_skip(HBits& h, int nb, uint32_t) { hb_skip(h, nb); }
+
+template <bool LW = false>
 __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const uint8_t* sp, uint32_t sn, uint8_t* out, uint32_t outn, uint32_t k,
-                                              uint32_t lps, bool on PROF_PARM) {
+                                              uint32_t lps, bool on PROF_PARM, uint8_t* cbuf = nullptr) {
   int bad = 0;
   int top = 0;
   if (on) {
@@ -299,7 +386,10 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
     if (!rb_init(r, sp, sn)) bad = 1;
     top = (int)r.bits;
   }
-  HBits h{sp, 0, 0, {0, 0, 0, 0}, 0, 0, 0};
+  const uint32_t wl = threadIdx.x & 63;  // lane of the wavefront (k: lane of the stream)
+  typename std::conditional<LW, HBitsL, HBits>::type h{};
+  h.p = sp;
+  if constexpr (LW) h.cb = cbuf;
   const int B = (top + (int)lps - 1) / (int)lps;
   int pk = top - (int)k * B, pn = k + 1 == lps ? 0 : top - (int)(k + 1) * B;
   if (pk < 0) pk = 0;
@@ -325,15 +415,18 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
         bool met = false;
         if (round == 0) {
           uint32_t limit = 16, jj = 0;
-          while (h.pos > pn) {
+          for (bool stop = false;;) {
+          hb_refill(h, !stop && h.pos > pn, wl);
+          while (h.pos > pn && hb_ready(h)) {
             const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
             const int nb = (int)(e >> 8);
             if (nb == 0) {  // not a table zstd builds: no progress possible
               bad = 1;
+              stop = true;
               break;
             }
             cnt++;
-            hb_skip(h, nb);
+            hb_skip(h, nb, wl);
             if (cnt == limit) {
               if (jj == 0) ck0 = h.pos;
               else if (jj == 1) ck1 = h.pos;
@@ -343,10 +436,14 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
               limit <<= 2;
             }
           }
+          if (!LW || stop || h.pos <= pn) break;
+          }
         } else {
           // (marks are only trusted in round 1: later rounds -- rare -- decode their segment whole)
           uint32_t jj = round == 1 ? 0u : 4u;
-          while (h.pos > pn) {
+          for (bool stop = false;;) {
+          hb_refill(h, !stop && h.pos > pn, wl);
+          while (h.pos > pn && hb_ready(h)) {
             if (jj < 4) {
               int ck = jj == 0 ? ck0 : (jj == 1 ? ck1 : (jj == 2 ? ck2 : ck3));
               while (jj < 4 && h.pos < ck) {  // passed without standing on it (a mark never reached is -1: below everything)
@@ -355,6 +452,7 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
               }
               if (jj < 4 && h.pos == ck) {
                 met = true;
+                stop = true;
                 break;
               }
             }
@@ -362,10 +460,13 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
             const int nb = (int)(e >> 8);
             if (nb == 0) {
               bad = 1;
+              stop = true;
               break;
             }
             cnt++;
-            hb_skip(h, nb);
+            hb_skip(h, nb, wl);
+          }
+          if (!LW || stop || h.pos <= pn) break;
           }
           if (met) {
             cnt += cnt_old - (16u << (2 * jj));  // the old path had 16 * 4^jj symbols above this mark
@@ -405,7 +506,9 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
     // (bytes up to the boundary one by one)
     uint32_t head = (uint32_t)((16u - ((uint32_t)(uintptr_t)(out + i) & 15u)) & 15u);
     hb_seek(h, start);
-    while (h.pos > pn) {
+    for (;;) {
+    hb_refill(h, h.pos > pn, wl);
+    while (h.pos > pn && hb_ready(h)) {
       const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
       const int nb = (int)(e >> 8);
       if (head) {
@@ -422,7 +525,9 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
           acc0 = acc1 = 0;
         }
       }
-      hb_skip(h, nb);
+      hb_skip(h, nb, wl);
+    }
+    if (!LW || h.pos <= pn) break;
     }
     for (uint32_t t = 0; t < nacc; t++) out[i + t] = (uint8_t)((t < 8 ? acc0 >> (8 * t) : acc1 >> (8 * (t - 8))));
   }

@@ -89,6 +89,7 @@ struct ZEntLds {
   uint16_t next[256];
   uint8_t sym[512];        // symbol of every cell while a table is being built
   __attribute__((aligned(4))) uint8_t stage[128];  // a table description on its way from memory to the parser
+  static constexpr bool kLitWindow = false;  // (literals by this kernel -- few blocks -- read their Huffman streams from memory: HBits)
 };
 
 // FSE decoding table with the symbol's extra bits and base value folded into every cell.  which: 0 LL, 1 OF, 2 ML.
@@ -254,7 +255,9 @@ __device__ __forceinline__ long zhuf_tree(LDS& L, const uint8_t* q, uint32_t qn,
     if (c < 0) return -1;
     if (fse_build_dev(L.h.wt, L.norm, nsym, log, L.next, lane)) return -1;
     RBits r;
-    if (!rb_init(r, q + 1 + c, hb - (uint32_t)c)) return -1;
+    // (the weights' bit stream lies in the staged copy of the description -- hb < 128 bytes, all of them staged by
+    // fse_read_ncount_dev --: its ~16 window reloads are LDS reads, not a chain of memory round trips, 100 us a block)
+    if (!rb_init(r, L.stage + c, hb - (uint32_t)c)) return -1;
     uint32_t s1 = (uint32_t)rb_read(r, (uint32_t)log), s2 = (uint32_t)rb_read(r, (uint32_t)log);
     nw = 0;
     int fail = 0;
@@ -544,7 +547,8 @@ __device__ __forceinline__ int zstd_literals_job(LDS& L, const ZBlock& B, const 
     int bad = 0;
     const uint32_t regen = B.lit_regen;
     if (B.lit_streams == 1) {
-      bad = huf_decode_par(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true PROF_ARG);
+      if constexpr (LDS::kLitWindow) bad = huf_decode_par<true>(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true PROF_ARG, L.chunk);
+      else bad = huf_decode_par(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true PROF_ARG);
     } else {
       if (qn < 6) st = 13;
       else {
@@ -560,7 +564,8 @@ __device__ __forceinline__ int zstd_literals_job(LDS& L, const ZBlock& B, const 
             const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
             const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
             const uint32_t on = k < 3 ? seg : regen - 3 * seg;
-            bad = huf_decode_par(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true PROF_ARG);
+            if constexpr (LDS::kLitWindow) bad = huf_decode_par<true>(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true PROF_ARG, L.chunk);
+            else bad = huf_decode_par(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true PROF_ARG);
           }
         }
       }
@@ -658,15 +663,27 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
 // The Huffman phase needs a third of the LDS of zstd_entropy_kernel (whose allocation is sized by the FSE tables of the sequences
 // phase): 28 wavefronts per CU instead of 10.  The decoder is a chain of table lookups per lane -- what it needs is wavefronts
 // to switch to.  Job j = the literals of block j; status_out[n_blocks + j] as zstd_entropy_kernel writes it.
+#ifndef ZL_LDS_WINDOW
+#define ZL_LDS_WINDOW 1
+#endif
 struct ZLitLds {
-  struct {
-    uint16_t huf[2048];  // sym | nb << 8
-    uint8_t weights[256];
-    FseEnt wt[64];
-  } h;
-  int16_t norm[256];
-  uint16_t next[256];
-  __attribute__((aligned(4))) uint8_t stage[128];
+  union {
+    struct {
+      struct {
+        uint16_t huf[2048];  // sym | nb << 8
+        uint8_t weights[256];
+        FseEnt wt[64];
+      } h;
+      int16_t norm[256];
+      uint16_t next[256];
+      __attribute__((aligned(4))) uint8_t stage[128];
+    };
+    struct {  // ... behind the table, once it is built: every lane's piece of its Huffman stream (HBitsL)
+      uint16_t huf_[2048];
+      __attribute__((aligned(16))) uint8_t chunk[ZL_LDS_WINDOW ? 64 * ZL_CHUNK : 16];
+    };
+  };
+  static constexpr bool kLitWindow = ZL_LDS_WINDOW != 0;
 };
 extern "C" __global__ void __launch_bounds__(64) zstd_literals_kernel(const ZBlock* __restrict__ blocks, uint32_t n_blocks, uint32_t* status_out, uint32_t* progress) {
   __shared__ ZLitLds L;
