@@ -73,6 +73,10 @@ struct ZEntLds {
       uint8_t weights[256];
       FseEnt wt[64];
     } h;
+    struct {  // literals phase, behind the Huffman table and its description: every lane's piece of its stream (HBitsL, zstd_device.h)
+      __attribute__((aligned(16))) uint8_t lit_pad[4096 + 256 + 64 * 8];
+      __attribute__((aligned(16))) uint8_t chunk[64 * ZL_CHUNK];
+    };
     struct {  // sequences phase
       ZFse ll[512], ml[512], of[256];
       ZFse zero;           // all-zero cell for the lanes without a field
@@ -89,7 +93,7 @@ struct ZEntLds {
   uint16_t next[256];
   uint8_t sym[512];        // symbol of every cell while a table is being built
   __attribute__((aligned(4))) uint8_t stage[128];  // a table description on its way from memory to the parser
-  static constexpr bool kLitWindow = false;  // (literals by this kernel -- few blocks -- read their Huffman streams from memory: HBits)
+  static constexpr bool kLitWindow = true;
 };
 
 // FSE decoding table with the symbol's extra bits and base value folded into every cell.  which: 0 LL, 1 OF, 2 ML.
