@@ -295,7 +295,7 @@ __device__ __forceinline__ long zhuf_tree(LDS& L, const uint8_t* q, uint32_t qn,
     used = 1 + hb;
     wave_sync();
   }
-  if (huf_build_dev(L.h.huf, maxbits, L.h.weights, nw, lane)) return -1;
+  if (huf_build_dev(L.h.huf, maxbits, L.h.weights, nw, lane, reinterpret_cast<uint8_t*>(L.norm))) return -1;  // (norm: free once the weights are decoded)
   return (long)used;
 }
 
