@@ -59,48 +59,86 @@ __device__ __forceinline__ bool br_overrun(const BitRd& b) { return (uint64_t)b.
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t len) { return __builtin_bitreverse32(v) >> (32 - len); }
 
-// canonical Huffman from code lengths; returns <0 over-subscribed, 0 complete, >0 incomplete
+// canonical Huffman from code lengths; returns <0 over-subscribed, 0 complete, >0 incomplete.  By the whole wavefront: lane l
+// holds the lengths of symbols l, l + 64, ...; per length the symbols' count and every symbol's rank among them by ballots (the
+// canonical code of a symbol = the first code of its length + its rank); every cell of the fast table looks its code up -- the
+// length whose first `len` bits, reversed, fall into that length's range of codes.  (One lane used to do it all, its running
+// offsets in a private array -- scratch memory --: half a millisecond per dynamic block, most of the DEFLATE stage's time.)
 __device__ __forceinline__ int huff_build_dev(HuffTab& h, const uint8_t* lens, int n, uint32_t lane) {
-  for (uint32_t i = lane; i < 1024; i += 64) h.fast[i] = 0;
-  if (lane < 16) h.count[lane] = 0;
-  wave_sync();
+  uint32_t l[5], rank[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    const int i = (int)lane + 64 * r;
+    l[r] = i < n ? lens[i] : 0u;
+  }
+  uint32_t cnt[16], offs[17], first[16];
+  uint32_t used = 0;
+#pragma unroll
+  for (int len = 1; len < 16; len++) {
+    uint32_t seen = 0;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      const unsigned long long m = __ballot(l[r] == (uint32_t)len);
+      if (l[r] == (uint32_t)len) rank[r] = seen + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1));
+      seen += (uint32_t)__builtin_popcountll(m);
+    }
+    cnt[len] = seen;
+    used += seen;
+  }
+  cnt[0] = (uint32_t)n - used;
+  if (lane < 16) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int len = 0; len < 16; len++)
+      if ((int)lane == len) c = cnt[len];
+    h.count[lane] = (uint16_t)c;
+  }
   int left = 0;
-  if (lane == 0) {
-    for (int i = 0; i < n; i++) h.count[lens[i]]++;
-    uint16_t offs[16];
+  bool bad = false;
+  if (used != 0) {
     left = 1;
-    int bad = 0;
-    if (h.count[0] == n) {
-      left = 0;
-    } else {
-      for (int len = 1; len < 16; len++) {
-        left <<= 1;
-        left -= h.count[len];
-        if (left < 0) {
-          bad = 1;
-          break;
-        }
-      }
+#pragma unroll
+    for (int len = 1; len < 16; len++) {
       if (!bad) {
-        offs[1] = 0;
-        for (int len = 1; len < 15; len++) offs[len + 1] = offs[len] + h.count[len];
-        for (int i = 0; i < n; i++)
-          if (lens[i]) h.symbol[offs[lens[i]]++] = (uint16_t)i;
-        // fast table
-        uint32_t code = 0, idx = 0;
-        for (uint32_t len = 1; len <= 10; len++) {
-          for (uint32_t k = 0; k < h.count[len]; k++, idx++, code++) {
-            uint32_t sym = h.symbol[idx];
-            uint32_t r = bitrev(code, len);
-            for (uint32_t j = r; j < 1024; j += 1u << len) h.fast[j] = (uint16_t)((len << 12) | sym);
-          }
-          code <<= 1;
-        }
+        left <<= 1;
+        left -= (int)cnt[len];
+        if (left < 0) bad = true;
       }
     }
-    if (bad) left = -1;
   }
-  left = __shfl(left, 0);
+  if (bad || used == 0) {
+    for (uint32_t i = lane; i < 1024; i += 64) h.fast[i] = 0;
+    wave_sync();
+    return bad ? -1 : 0;
+  }
+  offs[1] = 0;
+  uint32_t code = 0;
+#pragma unroll
+  for (int len = 1; len < 16; len++) {
+    offs[len + 1] = offs[len] + cnt[len];
+    first[len] = code;
+    code = (code + cnt[len]) << 1;
+  }
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    if (l[r]) {
+      uint32_t o = 0;
+#pragma unroll
+      for (int len = 1; len < 16; len++)
+        if (l[r] == (uint32_t)len) o = offs[len];
+      h.symbol[o + rank[r]] = (uint16_t)(lane + 64u * r);
+    }
+  }
+  wave_sync();
+  for (uint32_t j = lane; j < 1024; j += 64) {
+    uint32_t e = 0;
+#pragma unroll
+    for (int len = 1; len <= 10; len++) {
+      const uint32_t d = bitrev(j & ((1u << len) - 1), (uint32_t)len) - first[len];
+      if (e == 0 && d < cnt[len]) e = ((uint32_t)len << 12) | h.symbol[offs[len] + d];
+    }
+    h.fast[j] = (uint16_t)e;
+  }
   wave_sync();
   return left;
 }
