@@ -266,7 +266,8 @@ struct orcgpu_ctx {
   // behind the table kernels of ALL lanes.  tables_gate: 0 = this lane has not recorded ev[7] yet, 1 = it has, 2 = it has no such kernel
   orcgpu_ctx* gate_peers[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
   int n_gate_peers = 0;
-  std::atomic<int> tables_gate{0};
+int call_z_lanes = -1;  // a call split over column lanes: its Zstandard path decided for the call as a whole (1 table scale, 0 one wavefront per block), -1: every lane by its own count
+    std::atomic<int> tables_gate{0};
   uint32_t last_expand_launches = 0;
   // ---- staging pipeline (lane 0 only): a copy stream, two pinned pieces filled by a few host threads while the other one
   // is on its way to HBM, a pool of stripe arenas ----
@@ -689,6 +690,7 @@ struct ColPlan {
 
 struct Plan {
   int lane_id = 0;
+  int call_z_lanes = -1;  // (orcgpu_ctx::call_z_lanes of the lane that plans)
   std::vector<orcgpu_staged*> stripes;
   std::vector<orcgpu_result*> results;
   std::vector<ColPlan> cols;
