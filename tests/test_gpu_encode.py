@@ -203,3 +203,25 @@ def test_column_with_device_buffers():
         assert buf.tobytes() == stream
     finally:
         res.free()
+
+
+def test_encode_argument_errors():
+    from orc_rust_amd import capi
+    c = G.ctx()
+    n = C.c_uint64(7)
+    v = np.arange(10, dtype=np.int64)
+    assert c.L.orcgpu_encode_rle2(c.h, None, 10, 8, 1, 0, None, 0, C.byref(n)) == 101          # values missing
+    assert c.L.orcgpu_encode_rle2(c.h, v.ctypes.data, 10, 8, 1, 0, None, 0, None) == 101       # nowhere to put the size
+    assert c.L.orcgpu_encode_byte_rle(c.h, None, 0, 0, None, 0, C.byref(n)) == 0 and n.value == 0
+    assert c.L.orcgpu_encode_boolean(c.h, None, 0, 0, None, 0, C.byref(n)) == 0 and n.value == 0
+    streams = (capi.EncStream * 3)()
+    ns = C.c_uint32(9)
+    col = capi.EncColumn(99, 0, 10, None, v.ctypes.data, None)                                  # an Arrow type the reference's writer does not take
+    assert c.L.orcgpu_encode_column(c.h, C.byref(col), streams, C.byref(ns)) == 7 and ns.value == 0   # UnsupportedTypeVariant
+    col = capi.EncColumn(capi.ARROW["utf8"], 0, 10, None, v.ctypes.data, None)                  # strings without offsets
+    assert c.L.orcgpu_encode_column(c.h, C.byref(col), streams, C.byref(ns)) == 101
+    offs = np.array([5, 3], dtype=np.int32)                                                     # offsets that go backwards
+    col = capi.EncColumn(capi.ARROW["utf8"], 0, 1, None, v.ctypes.data, offs.ctypes.data)
+    assert c.L.orcgpu_encode_column(c.h, C.byref(col), streams, C.byref(ns)) == 101
+    # the context still encodes afterwards
+    assert c.encode_rle2(v, 8, True) == O.enc_rle2(v, 8, True)
