@@ -4,8 +4,12 @@
 // bytes are stored by lane 0, matches are copied by all lanes.
 #pragma once
 
+#ifndef HUFF_FAST_BITS
+#define HUFF_FAST_BITS 10  // (11: fewer trips through the long-code search, but 4 KiB more LDS per chunk -- lineitem / zlib SF 4 30.3 -> 32.7 ms)
+#endif
+#define HUFF_FAST_SIZE (1u << HUFF_FAST_BITS)
 struct HuffTab {
-  uint16_t fast[1024];  // (len << 12) | symbol for codes of <= 10 bits, 0 = long code
+  uint16_t fast[HUFF_FAST_SIZE];  // (len << 12) | symbol for codes of <= HUFF_FAST_BITS bits, 0 = long code
   uint16_t count[16];
   uint16_t symbol[320];
 };
@@ -107,7 +111,7 @@ __device__ __forceinline__ int huff_build_dev(HuffTab& h, const uint8_t* lens, i
     }
   }
   if (bad || used == 0) {
-    for (uint32_t i = lane; i < 1024; i += 64) h.fast[i] = 0;
+    for (uint32_t i = lane; i < HUFF_FAST_SIZE; i += 64) h.fast[i] = 0;
     wave_sync();
     return bad ? -1 : 0;
   }
@@ -130,10 +134,10 @@ __device__ __forceinline__ int huff_build_dev(HuffTab& h, const uint8_t* lens, i
     }
   }
   wave_sync();
-  for (uint32_t j = lane; j < 1024; j += 64) {
+  for (uint32_t j = lane; j < HUFF_FAST_SIZE; j += 64) {
     uint32_t e = 0;
 #pragma unroll
-    for (int len = 1; len <= 10; len++) {
+    for (int len = 1; len <= HUFF_FAST_BITS; len++) {
       const uint32_t d = bitrev(j & ((1u << len) - 1), (uint32_t)len) - first[len];
       if (e == 0 && d < cnt[len]) e = ((uint32_t)len << 12) | h.symbol[offs[len] + d];
     }
@@ -145,7 +149,7 @@ __device__ __forceinline__ int huff_build_dev(HuffTab& h, const uint8_t* lens, i
 
 __device__ __forceinline__ int huff_decode_dev(BitRd& b, const HuffTab& h) {
   if (b.bc < 15) br_refill(b);
-  uint32_t e = h.fast[b.bb & 1023];
+  uint32_t e = h.fast[b.bb & (HUFF_FAST_SIZE - 1)];
   if (e) {
     uint32_t l = e >> 12;
     b.bb >>= l;
@@ -184,13 +188,13 @@ __device__ __forceinline__ int inflate_codes_dev(BitRd& b, LzOut& o, uint32_t ca
     // Literals, up to four per trip: four chained table lookups (a code of the fast table is at most 10
     // bits), one 4-byte store into the ring by lane 0, one round of bookkeeping.  Anything else -- a
     // long code, a length symbol, end of block -- leaves the trip to the one-symbol path below.
-    if (b.bc < 40) br_refill(b);
+    if (b.bc < 4 * HUFF_FAST_BITS) br_refill(b);
     const uint32_t rpos = (uint32_t)o.out & o.rmask;
-    if (b.bc >= 40 && o.out + 4 <= cap && rpos + 4 <= o.rmask + 1) {
+    if (b.bc >= 4 * HUFF_FAST_BITS && o.out + 4 <= cap && rpos + 4 <= o.rmask + 1) {
       uint32_t acc = 0, k = 0, used = 0;
 #pragma unroll
       for (int t = 0; t < 4; t++) {
-        const uint32_t e = lc.fast[(uint32_t)(b.bb >> used) & 1023];
+        const uint32_t e = lc.fast[(uint32_t)(b.bb >> used) & (HUFF_FAST_SIZE - 1)];
         if (e == 0 || (e & 0xfff) >= 256) break;
         acc |= (e & 0xff) << (8 * k);
         k++;

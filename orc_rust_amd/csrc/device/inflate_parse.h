@@ -49,10 +49,10 @@ __device__ __forceinline__ void inf_long_codes(InfLong& g, const HuffTab& h, uin
     uint32_t code = 0, index = 0;
     for (int len = 1; len < 16; len++) {
       // (canonical codes: the first code of a length = (first of the length before + its count) << 1)
-      if (len >= 11) {
-        g.first[len - 11] = (uint16_t)code;
-        g.count[len - 11] = h.count[len];
-        g.index[len - 11] = (uint16_t)index;
+      if (len > HUFF_FAST_BITS) {
+        g.first[len - HUFF_FAST_BITS - 1] = (uint16_t)code;
+        g.count[len - HUFF_FAST_BITS - 1] = h.count[len];
+        g.index[len - HUFF_FAST_BITS - 1] = (uint16_t)index;
       }
       code = (code + h.count[len]) << 1;
       index += h.count[len];
@@ -70,11 +70,11 @@ struct InfTok {
 __device__ __forceinline__ int inf_slow(uint64_t bits, const HuffTab& h, const InfLong& g, uint32_t& used) {
   const uint32_t r = __builtin_bitreverse32((uint32_t)bits) >> 17;  // the first 15 bits, the first one on top
 #pragma unroll
-  for (int k = 0; k < 5; k++) {
-    const uint32_t c = r >> (4 - k);  // the first 11 + k bits as a code
+  for (int k = 0; k < 15 - HUFF_FAST_BITS; k++) {
+    const uint32_t c = r >> (14 - HUFF_FAST_BITS - k);  // the first HUFF_FAST_BITS + 1 + k bits as a code
     const uint32_t d = c - g.first[k];
     if (d < g.count[k]) {
-      used = 11u + (uint32_t)k;
+      used = HUFF_FAST_BITS + 1u + (uint32_t)k;
       return h.symbol[g.index[k] + d];
     }
   }
@@ -92,7 +92,7 @@ __device__ __forceinline__ InfTok inf_token(const InfLds<T>& L, const uint8_t* w
   InfTok t{3, 0, 0, 0};
   uint32_t used;
   int sym;
-  uint32_t e = lc.fast[(uint32_t)v & 1023];
+  uint32_t e = lc.fast[(uint32_t)v & (HUFF_FAST_SIZE - 1)];
   if (e) {
     used = e >> 12;
     sym = (int)(e & 0xfff);
@@ -118,7 +118,7 @@ __device__ __forceinline__ InfTok inf_token(const InfLds<T>& L, const uint8_t* w
   used += le;
   uint32_t du;
   int ds;
-  e = dc.fast[(uint32_t)(v >> used) & 1023];
+  e = dc.fast[(uint32_t)(v >> used) & (HUFF_FAST_SIZE - 1)];
   if (e) {
     du = e >> 12;
     ds = (int)(e & 0xfff);
