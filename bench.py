@@ -123,6 +123,9 @@ def build_workload(args, rank, world):
         stripe_rows = [min(W.LINEITEM_STRIPE_ROWS, rows - lo) for lo in range(0, rows, W.LINEITEM_STRIPE_ROWS)]
         units, loads = shard.unit_shard(stripe_rows, W.LINEITEM_ARROW_BYTES_PER_ROW, world)
         mine = units[rank]
+        if args.columns:
+            keep = {int(c) - 1 for c in args.columns.split(",")}
+            mine = [u for u in mine if u[1] in keep]
         desc = "all 16 columns of every stripe" if world == 1 else "(stripe, column) units x%d, LPT by Arrow bytes (not whole columns: l_comment alone is 18 %% of the bytes)" % world
         by_stripe = {}
         for s_, c_ in mine:
@@ -437,6 +440,7 @@ def spawn_ranks(args):
 # "walk" / "present" / "finish" are many kernels (and, beside another lane, waits for CU slots): phases, never the dominant kernel.
 ROOF_KERNELS = {
     "seq": "zstd_seq_quads_kernel (Zstandard FSE sequences, four lanes per block; events around the kernel alone)",
+    "lit": "zstd_literals_kernel (Zstandard Huffman literals, beside the sequences kernel on a stream of its own; events around the kernel alone)",
     "exec": {"zstd": "lz_exec_wave_kernel / lz_exec_kernel (LZ77 execution of Zstandard sequences)", "snappy": "lz_exec_tokens_kernel (LZ77 execution, one workgroup per chunk)",
              "lz4": "lz_exec_tokens_kernel (LZ77 execution, one workgroup per chunk)", "zlib": "lz_exec_kernel + decompress_deflate_kernel (DEFLATE execution)"},
     "stage1": {"zstd": "zstd_entropy_kernel (FSE sequences + Huffman literals, one wavefront per block)", "snappy": "lz_parse_kernel (token stage, one workgroup per chunk)",
@@ -445,7 +449,7 @@ ROOF_KERNELS = {
     "walk_short": "rle_walk_short_kernel (run boundaries of short-run streams: every byte position parsed, pointer doubling)",
     "dict_emit": "dict_emit_kernel (dictionary keys -> Utf8 offsets + value bytes)",
 }
-PMC_NAMES = {"seq": "zstd_seq_quads_kernel", "exec": "lz_exec_wave_kernel", "stage1": "zstd_entropy_kernel", "expand": "rle2_expand_kernel",
+PMC_NAMES = {"seq": "zstd_seq_quads_kernel", "lit": "zstd_literals_kernel", "exec": "lz_exec_wave_kernel", "stage1": "zstd_entropy_kernel", "expand": "rle2_expand_kernel",
              "walk_short": "rle_walk_short_kernel", "dict_emit": "dict_emit_kernel"}
 
 
@@ -473,7 +477,7 @@ def roofline_of(lane_acc, comp, workload, step_algo_bytes):
     `achieved` = (sum over the lanes' launches of the algorithmic bytes THAT launch works for: the lane's staged stream bytes in +
     its Arrow bytes out) / (sum of those launches' durations) = algorithmic bytes per launch / average launch duration."""
     best = None
-    for key in ("seq", "exec", "stage1", "expand", "walk_short", "dict_emit"):
+    for key in ("seq", "lit", "exec", "stage1", "expand", "walk_short", "dict_emit"):
         if key == "stage1" and any(a["seq"] > 0 for a in lane_acc.values()):
             continue  # (table scale: the first stage is the table kernel + the sequences kernel, priced as "seq")
         ls = [a for a in lane_acc.values() if a[key] > 0 and a["steps"]]
@@ -505,7 +509,7 @@ def lanes_of(lane_acc):
         a = lane_acc[l]
         n = max(1, a["steps"])
         out.append({"lane": l, "stream_bytes": a["stream_bytes"] // n, "arrow_bytes": a["arrow_bytes"] // n, "host_ms_before_first_launch": round(a["start_ms"] / n, 3),
-                    "device_ms": round(a["total_ms"] / n, 3), "zstd_tables_ms": round(a["tables"] / n, 3), "zstd_seq_quads_kernel_ms": round(a["seq"] / n, 3),
+                    "device_ms": round(a["total_ms"] / n, 3), "zstd_tables_ms": round(a["tables"] / n, 3), "zstd_seq_quads_kernel_ms": round(a["seq"] / n, 3), "zstd_literals_kernel_ms": round(a["lit"] / n, 3),
                     "stage1_ms": round(a["stage1"] / n, 3), "exec_kernel_ms": round(a["exec"] / n, 3), "walk_ms": round(a["walk"] / n, 3),
                     "expand_ms": round(a["expand"] / n, 3), "finish_ms": round(a["finish"] / n, 3),
                     "rle_walk_short_kernel_ms": round(a["walk_short"] / n, 3), "dict_emit_kernel_ms": round(a["dict_emit"] / n, 3)})
@@ -528,6 +532,7 @@ def main():
     ap.add_argument("--sf", type=float, default=0.0, help="lineitem: TPC-H scale factor per GPU (weak) / of the table (strong); default 12.5 = one GPU's share of C4's SF100")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every GPU gets a one-GPU share, the table grows with N (N = 8: C4's SF100); strong: one fixed table sharded over the ranks")
+    ap.add_argument("--columns", default="", help="lineitem, profiling runs: decode only these columns (1-based positions, e.g. 1,4,16) of every stripe")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--skip-check", action="store_true", help="profiling runs: skip the checks before timing")
     ap.add_argument("--no-e2e", action="store_true", help="profiling runs: skip the pipelined host-to-host measurement behind the timed region")
@@ -628,7 +633,7 @@ def main():
             for k, v in ctx.phase_ms().items():
                 phase[k] += v
             for ls in ctx.lane_stats():
-                a = lane_acc.setdefault(ls["lane"], {"steps": 0, "stream_bytes": 0, "arrow_bytes": 0, "start_ms": 0.0, "total_ms": 0.0, "seq": 0.0, "exec": 0.0,
+                a = lane_acc.setdefault(ls["lane"], {"steps": 0, "stream_bytes": 0, "arrow_bytes": 0, "start_ms": 0.0, "total_ms": 0.0, "seq": 0.0, "lit": 0.0, "exec": 0.0,
                                                      "stage1": 0.0, "tables": 0.0, "expand": 0.0, "walk": 0.0, "finish": 0.0, "walk_short": 0.0, "dict_emit": 0.0})
                 a["steps"] += 1
                 a["stream_bytes"] += ls["stream_bytes"]
@@ -636,6 +641,7 @@ def main():
                 a["start_ms"] += ls["start_ms"]
                 a["total_ms"] += ls["total_ms"]
                 a["seq"] += ls["seq_kernel_ms"]
+                a["lit"] += ls["literals_kernel_ms"]
                 a["exec"] += ls["exec_kernel_ms"]
                 a["stage1"] += ls["phase_ms"]["decompress_stage1"]
                 a["tables"] += ls["phase_ms"]["decompress_tables"]

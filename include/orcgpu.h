@@ -167,6 +167,12 @@ orcgpu_ctx* orcgpu_open(int device, const orcgpu_opts* opts);
 void orcgpu_close(orcgpu_ctx* ctx);
 const char* orcgpu_last_error(const orcgpu_ctx* ctx);
 const char* orcgpu_version(void);
+/* The binary interface a caller was built against: bumped whenever a struct of this header changes size or layout, or an entry
+ * point changes its meaning.  3 (round 6): orcgpu_lane_stats gained literals_kernel_ms; 2 (round 5): orcgpu_reader_next_batch
+ * ends with ORCGPU_END_OF_FILE (110) instead of 1, orcgpu_stream gained skip_bits.  A binding checks orcgpu_abi_version() ==
+ * ORCGPU_ABI_VERSION once, after loading the library. */
+#define ORCGPU_ABI_VERSION 3
+int orcgpu_abi_version(void);
 
 /* ---- staging: host stream bytes -> HBM --------------------------------------------------------- */
 /* Copies every stream of the stripe into one HBM arena (taken from a pool) and scans the 3-byte chunk headers
@@ -460,6 +466,8 @@ int orcgpu_last_phase_ms(const orcgpu_ctx* ctx, float* ms, uint32_t n);
  *                  the wait for the literals kernel that runs beside it); 0 when the call had no such launch
  *   exec_kernel_ms the LZ77 execution kernel(s) of the lane (lz_exec_wave_kernel / lz_exec_kernel / lz_exec_tokens_kernel)
  *   walk_short_kernel_ms, dict_emit_kernel_ms   rle_walk_short_kernel / dict_emit_kernel alone (events around the launch; 0: none)
+ *   literals_kernel_ms   Zstandard at table scale: zstd_literals_kernel alone, on the stream it runs on beside the sequences kernel
+ *                  (an event in front of it, behind the wait for the FSE tables, and one behind it); 0 when the call had no such launch
  * Returns ORCGPU_INVALID_ARGUMENT for a lane the last call did not run. */
 typedef struct orcgpu_lane_stats {
   uint32_t lane, n_lanes;
@@ -468,6 +476,7 @@ typedef struct orcgpu_lane_stats {
   float phase_ms[ORCGPU_N_PHASES];
   float seq_kernel_ms, exec_kernel_ms;
   float walk_short_kernel_ms, dict_emit_kernel_ms;
+  float literals_kernel_ms;
 } orcgpu_lane_stats;
 int orcgpu_last_lane_stats(const orcgpu_ctx* ctx, uint32_t lane, orcgpu_lane_stats* out);
 

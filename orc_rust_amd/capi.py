@@ -17,7 +17,7 @@ ERR_NAMES = {
 }
 COMP = {"none": 0, "zlib": 1, "snappy": 2, "lzo": 3, "lz4": 4, "zstd": 5}
 EXPORTS = [
-    "orcgpu_open", "orcgpu_close", "orcgpu_last_error", "orcgpu_version", "orcgpu_stage_stripe", "orcgpu_staged_free",
+    "orcgpu_open", "orcgpu_close", "orcgpu_last_error", "orcgpu_version", "orcgpu_abi_version", "orcgpu_stage_stripe", "orcgpu_staged_free",
     "orcgpu_staged_bytes", "orcgpu_decode_staged", "orcgpu_stripe_decode", "orcgpu_result_free", "orcgpu_result_status",
     "orcgpu_result_rows", "orcgpu_result_batches", "orcgpu_result_arrow_bytes", "orcgpu_result_batch_view",
     "orcgpu_result_copy_batch", "orcgpu_result_fetch", "orcgpu_result_fetch_async", "orcgpu_result_select", "orcgpu_selection_batches", "orcgpu_timezone_offsets", "orcgpu_result_export_batch", "orcgpu_last_timing", "orcgpu_last_phase_ms", "orcgpu_last_lane_stats", "orcgpu_encode_rle2_i64", "orcgpu_encode_rle2", "orcgpu_encode_byte_rle", "orcgpu_encode_boolean", "orcgpu_encode_column", "orcgpu_encode_fetch",
@@ -60,7 +60,8 @@ class StripeDesc(C.Structure):
 class LaneStats(C.Structure):
     _fields_ = [("lane", C.c_uint32), ("n_lanes", C.c_uint32), ("stream_bytes", C.c_uint64), ("arrow_bytes", C.c_uint64),
                 ("start_ms", C.c_float), ("total_ms", C.c_float), ("phase_ms", C.c_float * 7), ("seq_kernel_ms", C.c_float),
-                ("exec_kernel_ms", C.c_float), ("walk_short_kernel_ms", C.c_float), ("dict_emit_kernel_ms", C.c_float)]
+                ("exec_kernel_ms", C.c_float), ("walk_short_kernel_ms", C.c_float), ("dict_emit_kernel_ms", C.c_float),
+                ("literals_kernel_ms", C.c_float)]
 
 
 class RowSelector(C.Structure):
@@ -121,6 +122,7 @@ class BatchView(C.Structure):
 
 
 _lib = None
+ABI_VERSION = 3  # include/orcgpu.h: ORCGPU_ABI_VERSION
 
 
 def lib_path():
@@ -133,6 +135,8 @@ def load():
     if _lib is not None:
         return _lib
     so = os.environ.get("ORCGPU_LIB") or _build.build()
+    # the host's setting to make, before the process's first HIP call (INTEGRATION.md "Runtime setting"): the decoder's streams side by side
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "TZDIR" not in os.environ and not os.path.isdir("/usr/share/zoneinfo"):
         # writer time zones are resolved by the library through the system's tz database; without one, use the tzdata package's
         try:
@@ -147,6 +151,8 @@ def load():
     L.orcgpu_last_error.restype = C.c_char_p
     L.orcgpu_last_error.argtypes = [C.c_void_p]
     L.orcgpu_version.restype = C.c_char_p
+    if L.orcgpu_abi_version() != ABI_VERSION:
+        raise RuntimeError("liborcgpu.so speaks ABI %d, this binding %d (include/orcgpu.h: ORCGPU_ABI_VERSION)" % (L.orcgpu_abi_version(), ABI_VERSION))
     L.orcgpu_stage_stripe.argtypes = [C.c_void_p, C.POINTER(StripeDesc), C.POINTER(C.c_void_p)]
     L.orcgpu_staged_free.argtypes = [C.c_void_p]
     L.orcgpu_staged_bytes.restype = C.c_uint64
@@ -370,7 +376,8 @@ class Context:
                         "start_ms": float(st.start_ms), "total_ms": float(st.total_ms),
                         "phase_ms": dict(zip(self.PHASES + ("decompress_stage1", "decompress_tables"), [float(x) for x in st.phase_ms])),
                         "seq_kernel_ms": float(st.seq_kernel_ms), "exec_kernel_ms": float(st.exec_kernel_ms),
-                        "walk_short_kernel_ms": float(st.walk_short_kernel_ms), "dict_emit_kernel_ms": float(st.dict_emit_kernel_ms)})
+                        "walk_short_kernel_ms": float(st.walk_short_kernel_ms), "dict_emit_kernel_ms": float(st.dict_emit_kernel_ms),
+                        "literals_kernel_ms": float(st.literals_kernel_ms)})
             k += 1
             if k >= st.n_lanes:
                 break

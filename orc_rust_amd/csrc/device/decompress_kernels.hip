@@ -272,37 +272,81 @@ extern "C" __global__ void __launch_bounds__(64) decompress_lzo_kernel(ChunkDesc
   }
 }
 
-// One workgroup per stream: make the plain chunks contiguous (they already are unless a chunk in
-// the middle came out shorter than its slot), publish the plain length, stop at the first bad chunk.
+// One WAVEFRONT per stream: make the plain chunks contiguous (they already are unless a chunk in the middle came out shorter
+// than its slot), publish the plain length, stop at the first bad chunk.
 // chunk_start (optional): per chunk, where its plain bytes start in the stream (for the verified run starts of rle_hint_kernel)
-extern "C" __global__ void __launch_bounds__(256) decompress_finalize_kernel(const ChunkDesc* chunks, const StreamDesc* streams, uint64_t* scalars,
-                                                                             uint32_t* chunk_start) {
-  StreamDesc s = streams[blockIdx.x];
+// The chunks of a stream are looked at 64 at a time, one per lane: a stream of hundreds of chunks costs a few memory round trips,
+// not one per chunk (round 5: a serial loop).  A workgroup of ONE wavefront, because this kernel starts while the other column
+// lane's execution kernel -- single-wavefront workgroups, 24 a CU -- still fills the device: a 256-thread workgroup waits for four
+// free slots on one CU, which that kernel never leaves (round 5 and the first parallel version alike: 3.7 ms in the queue at SF 12.5
+// for 0.05 ms of work).  Only a chunk that has to move is handled by the whole wavefront, in stream order.
+extern "C" __global__ void __launch_bounds__(64) decompress_finalize_kernel(const ChunkDesc* chunks, const StreamDesc* streams, uint64_t* scalars,
+                                                                            uint32_t* chunk_start) {
+  const StreamDesc s = streams[blockIdx.x];
+  const uint32_t t = threadIdx.x;
   uint64_t total = 0;
   uint32_t err = s.framing_error ? ORC_E_IO : 0;
-  for (uint32_t i = 0; i < s.n_chunks; i++) {
-    const ChunkDesc& c = chunks[s.first_chunk + i];
-    if (chunk_start && threadIdx.x == 0) chunk_start[s.first_chunk + i] = (uint32_t)(total > 0xffffffffull ? 0xffffffffull : total);
-    if (c.status) {
-      err = c.status;
-      break;
+  for (uint32_t i0 = 0; i0 < s.n_chunks; i0 += 64) {
+    const uint32_t i = i0 + t;
+    uint32_t status = 0, out_len = 0;
+    const uint8_t* dst = nullptr;
+    if (i < s.n_chunks) {
+      const ChunkDesc& c = chunks[s.first_chunk + i];
+      status = c.status;
+      out_len = c.out_len;
+      dst = c.dst;
     }
-    uint8_t* want = s.base + total;
-    if (c.dst != want && c.out_len) {
-      // move left, ascending addresses: safe for overlapping ranges because want < c.dst
-      for (uint32_t k = 0; k < c.out_len; k += 256 * 8) {
-        uint32_t p = k + threadIdx.x * 8;
-        uint64_t v = 0;
-        uint32_t nb = p < c.out_len ? (c.out_len - p < 8 ? c.out_len - p : 8) : 0;
-        for (uint32_t t = 0; t < nb; t++) v |= (uint64_t)c.dst[p + t] << (8 * t);
-        __syncthreads();
-        for (uint32_t t = 0; t < nb; t++) want[p + t] = (uint8_t)(v >> (8 * t));
-        __syncthreads();
+    const unsigned long long bad_m = __ballot(status != 0);
+    const uint32_t first_bad = bad_m ? (uint32_t)__builtin_ctzll(bad_m) : 64u;
+    // inclusive scan of the tile's plain lengths (a chunk is at most a block size: 64 of them fit 32 bits)
+    uint32_t incl = out_len;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, d);
+      if (t >= d) incl += v;
+    }
+    const uint64_t start = total + incl - out_len;
+    if (i < s.n_chunks && t <= first_bad && chunk_start) chunk_start[s.first_chunk + i] = (uint32_t)(start > 0xffffffffull ? 0xffffffffull : start);
+    const unsigned long long move_m = __ballot(i < s.n_chunks && t < first_bad && out_len && dst != s.base + start);
+    const uint32_t n_here = s.n_chunks - i0 < 64 ? s.n_chunks - i0 : 64;
+    const uint32_t n_ok = first_bad < n_here ? first_bad : n_here;
+    if (move_m) {
+      // the rare case: chunk by chunk from the first one that is out of place
+      const uint32_t first_move = (uint32_t)__builtin_ctzll(move_m);
+      uint64_t at = total + (first_move ? (uint32_t)__shfl((int)incl, first_move - 1) : 0u);
+      for (uint32_t k = first_move; k < n_ok; k++) {
+        const uint32_t n = (uint32_t)__shfl((int)out_len, k);
+        const uint8_t* from = chunks[s.first_chunk + i0 + k].dst;
+        uint8_t* want = s.base + at;
+        if (from != want && n) {
+          // move left, ascending addresses: safe for overlapping ranges because want < from (a piece is read by every lane before
+          // any lane writes it: loads and stores of one wavefront leave in order, the fence keeps the compiler from mixing them)
+          for (uint32_t b = 0; b < n; b += 64 * 8) {
+            const uint32_t p = b + t * 8;
+            uint64_t v = 0;
+            const uint32_t nb = p < n ? (n - p < 8 ? n - p : 8) : 0;
+            if (nb == 8) v = ld_u64(from + p);
+            else
+              for (uint32_t q = 0; q < nb; q++) v |= (uint64_t)from[p + q] << (8 * q);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (nb == 8) st_u64(want + p, v);
+            else
+              for (uint32_t q = 0; q < nb; q++) want[p + q] = (uint8_t)(v >> (8 * q));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+        at += n;
       }
     }
-    total += c.out_len;
+    total += n_ok ? (uint32_t)__shfl((int)incl, n_ok - 1) : 0u;
+    if (first_bad < n_here) {
+      err = (uint32_t)__shfl((int)status, first_bad);
+      break;
+    }
   }
-  if (threadIdx.x == 0) {
+  if (t == 0) {
     scalars[s.len_idx] = total > s.skip ? total - s.skip : 0;
     if (err) scalars[s.err_idx] = err;
   }

@@ -28,6 +28,10 @@
 #define ORC_EXPAND_WAVES 4
 #endif
 
+// rle2_expand_short_kernel: blocks per wavefront whose bytes are staged in LDS, and the bytes behind them staged too (the window
+// of a header that starts in the group's last bytes, the payload of a short run that ends behind them)
+#define RLE_STAGE_BLKS 8u
+#define RLE_STAGE_TAIL 96u
 struct WaveLds {
   uint32_t start[65];
   uint32_t cstart[65];  // narrow keys: first 8-value chunk of every run slot (see the chunk pass of expand_group)
@@ -110,16 +114,20 @@ __device__ __forceinline__ void report(RleJob* j, uint64_t needed, uint64_t oi, 
 }
 
 // One value of a random-access run (SHORT_REPEAT, DIRECT, fixed DELTA, v1 run, byte run / literal).
-__device__ __forceinline__ int64_t decode_b1(uint32_t type, uint32_t w, int64_t base, int64_t dlt, const uint8_t* pp, uint32_t idx,
+// `ld8(byte offset)`: the 8 stream bytes at that offset from the run's payload, as loaded (little endian) -- from memory, or from
+// the wavefront's LDS copy of its blocks (rle2_expand_short_kernel).
+template <typename LD8>
+__device__ __forceinline__ int64_t decode_b1(uint32_t type, uint32_t w, int64_t base, int64_t dlt, LD8 ld8, uint32_t idx,
                                              bool is_signed, int nbits, bool& bad) {
   int64_t v;
   if (type == RT_SR || type == RT_B_RUN) {
     v = base;
   } else if (type == RT_DIRECT) {
-    uint64_t u = unpack_be(pp, idx, w);
+    const uint64_t bit = (uint64_t)idx * w;
+    uint64_t u = (__builtin_bswap64(ld8((uint32_t)(bit >> 3))) << (bit & 7)) >> (64 - w);  // unpack_be
     v = is_signed ? zigzag_n(u, nbits) : trunc_n((int64_t)u, nbits);
   } else if (type == RT_B_LIT) {
-    v = (int8_t)pp[idx];
+    v = (int8_t)(ld8(idx) & 0xff);
   } else if (type == RT_DELTA) {  // fixed delta (delta.rs:84-93)
     bool add = dlt > 0;
     int64_t mag = dlt < 0 ? (int64_t)(0 - (uint64_t)dlt) : dlt;
@@ -148,9 +156,9 @@ __device__ __forceinline__ void direct_pair_load(const uint8_t* pp, uint32_t i0,
   }
 }
 
-template <int CODEC, int OB, int NB = OB * 8>
+template <int CODEC, int OB, int NB = OB * 8, bool STAGED = false>
 __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, const uint64_t* scalars, uint32_t lg, WaveLds& L,
-                                             uint32_t lane PROF_PARM) {
+                                             uint32_t lane, uint8_t* stage PROF_PARM) {
   const uint8_t* data = as_global(j->data);
   void* out = as_global(j->out);
   const uint64_t len = scalars[j->len_idx];
@@ -162,6 +170,24 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
   const uint32_t G = j->group_size;
   const uint32_t eof_code = CODEC == CODEC_BYTE ? ORC_E_IO : ORC_E_OUT_OF_SPEC;
 
+  // STAGED (rle2_expand_short_kernel: groups of at most RLE_STAGE_BLKS blocks): the group's stream bytes [s0, s1) are copied to LDS
+  // once, with coalesced loads; run headers and the payloads of short runs are then read from there -- a header of a short-run
+  // stream costs an LDS access (~0.1 us) instead of a dependent trip to L2 (~1 us), and a block of such a stream holds ~200 of them
+  const uint64_t s0 = STAGED ? (uint64_t)lg * G * RLE_BLK : 0, s1 = STAGED ? (s0 + (uint64_t)G * RLE_BLK + RLE_STAGE_TAIL < len + 16 ? s0 + (uint64_t)G * RLE_BLK + RLE_STAGE_TAIL : len + 16) : 0;
+  if (STAGED) {
+    for (uint64_t o = s0 + lane * 16; o < s1; o += 1024) {
+      uint64_t v[2];
+      __builtin_memcpy(v, data + o, 16);  // (the last piece may reach 15 bytes behind s1 <= len + 16: inside the ORC_PAD bytes of slack every stream carries)
+      __builtin_memcpy(stage + (o - s0), v, 16);
+    }
+    wave_sync();
+  }
+  auto staged24 = [&](uint64_t p) -> bool { return STAGED && p >= s0 && p + 24 <= s1; };
+  // 8 stream bytes at `off`
+  auto ld8_at = [&](uint64_t off) -> uint64_t {
+    if (STAGED && off >= s0 && off + 8 <= s1) return ld_u64(stage + (off - s0));
+    return ld_u64(data + off);
+  };
   PROF_MARK(8);
   uint32_t lb = lg * G + lane;
   bool active = false, tail_owner = false;
@@ -195,10 +221,21 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
     } else if (active) {
       uint64_t p = pos, o = oi;
       for (uint32_t k = 0; k < K && p < end && o < needed; k++) {
-        RunHdr hh;
-        run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, hh);
         L.spos[lane * K + k] = p;
         L.soi[lane * K + k] = (uint32_t)o;
+        if (CODEC == CODEC_RLE2) {
+          // SHORT_REPEAT / DIRECT from the header's two bytes (rle2_hop2); whatever else there is takes the full parse
+          const uint32_t hw = staged24(p) ? (uint32_t)stage[p - s0] | ((uint32_t)stage[p - s0 + 1] << 8) : (uint32_t)data[p] | ((uint32_t)data[p + 1] << 8);
+          uint32_t fsz, fn;
+          if (rle2_hop2(hw & 0xff, hw >> 8, nbits, len - p, fsz, fn)) {
+            p += fsz;
+            o += fn;
+            continue;
+          }
+        }
+        RunHdr hh;
+        if (staged24(p)) run_parse<CODEC, false>(stage + (p - s0), len - p, is_signed, nbits, hh);
+        else run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, hh);
         if (hh.err) clean = false;
         p += hh.size;
         o += hh.n;
@@ -221,7 +258,8 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
     uint32_t cnt = 0, chunks = 0;
     if (has) {
       const uint64_t soi = L.soi[lane];
-      run_parse<CODEC, true>(data + sp, len - sp, is_signed, nbits, h);
+      if (staged24(sp)) run_parse<CODEC, true>(stage + (sp - s0), len - sp, is_signed, nbits, h);
+      else run_parse<CODEC, true>(data + sp, len - sp, is_signed, nbits, h);
       if (K == 1) {
         if (h.err) clean = false;
         pos = sp + h.size;
@@ -287,7 +325,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           hi = lo;
         } else {
           const uint64_t bit = (uint64_t)i0 * w;
-          uint64_t raw = __builtin_bswap64(ld_u64(data + L.pay[r] + (bit >> 3))) << (bit & 7);  // MSB-first bit stream (integer/util.rs:44-218)
+          uint64_t raw = __builtin_bswap64(ld8_at(L.pay[r] + (bit >> 3))) << (bit & 7);  // MSB-first bit stream (integer/util.rs:44-218)
 #pragma unroll
           for (int k = 0; k < 8; k++) {
             uint64_t v = raw >> (64 - w);  // unsigned, 1 <= w <= 8
@@ -334,7 +372,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           bool bad = false;
           int64_t v[8];
 #pragma unroll
-          for (int u = 0; u < 8; u++) v[u] = decode_b1(type, w, base, dlt, pp, i0 + u * 64 + lane, is_signed, nbits, bad);
+          for (int u = 0; u < 8; u++) v[u] = decode_b1(type, w, base, dlt, [&](uint32_t o) { return ld_u64(pp + o); }, i0 + u * 64 + lane, is_signed, nbits, bad);
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             uint64_t oo = o0 + i0 + u * 64 + lane;
@@ -389,8 +427,8 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
 #pragma unroll
             for (int u = 0; u < 4; u++) {
               uint32_t idx = i0 + u * 128 + 2 * lane;
-              va[u] = decode_b1(type, w, base, dlt, pp, idx, is_signed, nbits, bad);
-              vb[u] = decode_b1(type, w, base, dlt, pp, idx + 1, is_signed, nbits, bad);
+              va[u] = decode_b1(type, w, base, dlt, [&](uint32_t o) { return ld_u64(pp + o); }, idx, is_signed, nbits, bad);
+              vb[u] = decode_b1(type, w, base, dlt, [&](uint32_t o) { return ld_u64(pp + o); }, idx + 1, is_signed, nbits, bad);
             }
           }
 #pragma unroll
@@ -413,7 +451,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           bool bad = false;
           int64_t v[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) v[u] = decode_b1(type, w, base, dlt, pp, i0 + u * 64 + lane, is_signed, nbits, bad);
+          for (int u = 0; u < 4; u++) v[u] = decode_b1(type, w, base, dlt, [&](uint32_t o) { return ld_u64(pp + o); }, i0 + u * 64 + lane, is_signed, nbits, bad);
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             uint64_t oo = o0 + i0 + u * 64 + lane;
@@ -449,7 +487,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const uint32_t m = L.meta[rr[u]];
-          vv[u] = in[u] ? decode_b1(m & 0xff, (m >> 8) & 0xff, L.base[rr[u]], L.delta[rr[u]], data + L.pay[rr[u]], ix[u], is_signed, nbits, badv[u]) : 0;
+          vv[u] = in[u] ? decode_b1(m & 0xff, (m >> 8) & 0xff, L.base[rr[u]], L.delta[rr[u]], [&](uint32_t o) { return ld8_at(L.pay[rr[u]] + o); }, ix[u], is_signed, nbits, badv[u]) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -631,46 +669,54 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
   if (tail_owner && clean && pos >= len) report(j, needed, oi, eof_code | ORC_E_EOF, len);
 }
 
-template <int CODEC>
-__device__ __forceinline__ void expand_entry(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars, uint32_t total_groups) {
+template <int CODEC, bool STAGED = false>
+__device__ __forceinline__ void expand_entry(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars, uint32_t group_begin, uint32_t total_groups) {
   __shared__ WaveLds lds[4];
+  __shared__ __attribute__((aligned(16))) uint8_t stage_all[STAGED ? 4 : 1][STAGED ? RLE_STAGE_BLKS * RLE_BLK + RLE_STAGE_TAIL + 16 : 16];
   uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint32_t g = blockIdx.x * 4 + wv;
+  uint32_t g = group_begin + blockIdx.x * 4 + wv;
   if (g >= total_groups) return;
   PROF_BEGIN();
   RleJob* j = &jobs[group_job[g]];
   uint32_t lg = g - j->group0;
   if (lg >= j->ngroups) return;
+  uint8_t* stage = stage_all[STAGED ? wv : 0];
   PROF_MARK(9);
   if (CODEC == CODEC_BYTE) {
-    expand_group<CODEC, 1>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
+    expand_group<CODEC, 1, 8, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG);
   } else {
     // wave-uniform dispatch on the value width: the bodies are specialised at compile time
     switch (j->out_bytes) {
-      case 8: expand_group<CODEC, 8>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;
+      case 8: expand_group<CODEC, 8, 64, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG); break;
       case 4:
-        if (j->nbits == 64) expand_group<CODEC, 4, 64>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
-        else expand_group<CODEC, 4>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
+        if (j->nbits == 64) expand_group<CODEC, 4, 64, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG);
+        else expand_group<CODEC, 4, 32, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG);
         break;
       case 2:
-        if (j->nbits == 64) expand_group<CODEC, 2, 64>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
-        else expand_group<CODEC, 2>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
+        if (j->nbits == 64) expand_group<CODEC, 2, 64, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG);
+        else expand_group<CODEC, 2, 16, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG);
         break;
-      default: expand_group<CODEC, 1, 64>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;  // (one-byte dictionary keys)
+      default: expand_group<CODEC, 1, 64, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG); break;  // (one-byte dictionary keys)
     }
   }
   PROF_END();
 }
 
+// Groups [group_begin, total_groups) of the class's group table: the host puts the jobs whose groups are staged (short-run streams:
+// group_size <= RLE_STAGE_BLKS) behind the others, each kind gets its own launch.
 extern "C" __global__ void __launch_bounds__(256, ORC_EXPAND_WAVES) rle2_expand_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,
-                                                                      uint32_t total_groups) {
-  expand_entry<CODEC_RLE2>(jobs, group_job, blk, scalars, total_groups);
+                                                                      uint32_t group_begin, uint32_t total_groups) {
+  expand_entry<CODEC_RLE2>(jobs, group_job, blk, scalars, group_begin, total_groups);
+}
+extern "C" __global__ void __launch_bounds__(256, 3) rle2_expand_short_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,
+                                                                      uint32_t group_begin, uint32_t total_groups) {
+  expand_entry<CODEC_RLE2, true>(jobs, group_job, blk, scalars, group_begin, total_groups);
 }
 extern "C" __global__ void __launch_bounds__(256) rle1_expand_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,
-                                                                      uint32_t total_groups) {
-  expand_entry<CODEC_RLE1>(jobs, group_job, blk, scalars, total_groups);
+                                                                      uint32_t group_begin, uint32_t total_groups) {
+  expand_entry<CODEC_RLE1>(jobs, group_job, blk, scalars, group_begin, total_groups);
 }
 extern "C" __global__ void __launch_bounds__(256) byte_expand_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,
-                                                                      uint32_t total_groups) {
-  expand_entry<CODEC_BYTE>(jobs, group_job, blk, scalars, total_groups);
+                                                                      uint32_t group_begin, uint32_t total_groups) {
+  expand_entry<CODEC_BYTE>(jobs, group_job, blk, scalars, group_begin, total_groups);
 }

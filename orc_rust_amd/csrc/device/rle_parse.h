@@ -493,6 +493,22 @@ __device__ __forceinline__ bool rle2_lean(const Win24& win, int nbits, uint32_t&
   return ok;
 }
 
+// The two commonest RLE v2 headers -- SHORT_REPEAT and DIRECT -- from their first two bytes alone, branch-free: size and value
+// count of the run.  False for the other sub-encodings and for anything the full parse would reject (the caller then takes it).
+// What the expansion's chain walk costs per run in short-run streams (dictionary keys, order keys): ~20 instructions instead of
+// the full parse's few hundred, executed for the handful of lanes that own a block.
+__device__ __forceinline__ bool rle2_hop2(uint32_t h0, uint32_t h1, int nbits, uint64_t avail, uint32_t& sz, uint32_t& n) {
+  const uint32_t t = h0 >> 6;
+  const uint32_t bw = ((h0 >> 3) & 7) + 1;
+  const uint32_t w = rle2_width((h0 >> 1) & 31);
+  const uint32_t nn = (((h0 & 1) << 8) | h1) + 1;
+  const bool sr = t == RT_SR;
+  sz = sr ? 1 + bw : 2 + ((nn * w + 7) >> 3);
+  n = sr ? (h0 & 7) + 3 : nn;
+  const uint32_t width = sr ? bw * 8 : w;
+  return t <= RT_DIRECT && width <= (uint32_t)nbits && sz <= avail;
+}
+
 // ---- lean hop: (size, n) of the run at p, for the block walks ------------------------------------------
 // Identical to run_parse<CODEC, false> whenever that succeeds; anything unusual (errors, the last
 // bytes of the stream) is delegated to run_parse so that both always agree.

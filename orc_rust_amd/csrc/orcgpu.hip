@@ -255,6 +255,8 @@ struct orcgpu_ctx {
   bool kev_used[2] = {false, false};
   hipStream_t aux_stream = nullptr;   // the Zstandard execution kernel runs here, beside the entropy kernel on `stream`
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
+  hipEvent_t lit_ev[2] = {nullptr, nullptr};  // around zstd_literals_kernel on the stream it runs on (orcgpu_last_lane_stats)
+  bool lit_ev_used = false;
   float last_total_ms = 0, last_expand_ms = 0;
   float last_phase_ms[ORCGPU_N_PHASES] = {0, 0, 0, 0, 0, 0, 0};
   orcgpu_lane_stats last_stats{};     // this lane's part of the last call (orcgpu_last_lane_stats)
@@ -721,18 +723,18 @@ struct Plan {
 
 }  // namespace
 
-// The decoder runs its column lanes, the Zstandard literals kernel and the copies back on HIP streams of their own.  The runtime
-// maps streams onto 4 hardware queues unless told otherwise, and kernels that share a queue run one after the other whatever their
-// streams (measured: the literals kernel ran beside the sequences kernel only with more queues).  The setting is read when the HIP
-// runtime initialises, i.e. at the first HIP call of the process: the library asks for 8 when it is loaded, unless the host has
-// chosen a value itself.  A host that has touched HIP before loading the library must export GPU_MAX_HW_QUEUES=8 itself
-// (INTEGRATION.md); results do not depend on it, only how much of a call runs side by side.
-__attribute__((constructor)) static void orcgpu_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// GPU_MAX_HW_QUEUES: the decoder uses several HIP streams per context (column lanes, the literals stream, the copy-back stream); the
+// HIP runtime maps streams onto 4 hardware queues unless told otherwise, and kernels that share a queue run one after the other
+// whatever their streams (measured: the literals kernel ran beside the sequences kernel only with more queues).  The setting is
+// the HOST'S to make, before its first HIP call (`GPU_MAX_HW_QUEUES=8`; bench.py and the ctypes binding do it) --
+// round 5's library constructor that called setenv() changed the queue configuration of every other HIP user of the process and
+// raced with getenv() in other threads; it is gone.  Results never depend on the setting, only how much of a call runs side by side.
 
 // =================================================================================================
 extern "C" {
 
-const char* orcgpu_version(void) { return "orcgpu 0.1 (gfx950)"; }
+const char* orcgpu_version(void) { return "orcgpu 0.3 (gfx950)"; }
+int orcgpu_abi_version(void) { return ORCGPU_ABI_VERSION; }
 
 // `lane` > 0: the context of a column lane beside the caller's own (orcgpu_decode.inc).  The caller's own stream -- lane 0, which takes
 // the columns with the longest Zstandard chains -- is created at the highest stream priority: its sequences kernel lasts as long as
@@ -766,6 +768,11 @@ static orcgpu_ctx* open_ctx(int device, const orcgpu_opts* opts, int lane) {
         delete c;
         return nullptr;
       }
+  for (auto& e : c->lit_ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      delete c;
+      return nullptr;
+    }
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = (uint32_t)prop.multiProcessorCount;
@@ -815,6 +822,8 @@ void orcgpu_close(orcgpu_ctx* c) {
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : c->aux_ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->lit_ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& pr : c->kev)
     for (auto& e : pr)

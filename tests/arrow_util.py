@@ -9,6 +9,14 @@ import pyarrow as pa
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+# Columns the REFERENCE cannot decode (there is no expectation to pin on; oracle and GPU path must fail the way the reference
+# does): decimal64_v2*.orc are written with ORC 2.0's "decimal64" encoding -- DATA is an RLE v2 stream of i64, there is no
+# SECONDARY stream -- while decimal.rs:36-60 reads DATA as unbounded varints and the scales from a stream the stripe does not
+# hold (an empty one, stripe.rs:322-336): the first batch ends in OutOfSpec.  Column `a` (Int64) decodes; so does a column of
+# precision above 18 (`c` of decimal64_v2.orc), which keeps the classic encoding.
+REFERENCE_FAILS = {"decimal64_v2.orc": {"b", "d", "e"}, "decimal64_v2_cplusplus.orc": {"b", "c", "d", "e"}}
+
+
 def arrow_type(kind, precision=0, scale=0, ts_unit=3):
     unit = ["s", "ms", "us", "ns"][ts_unit]
     return {

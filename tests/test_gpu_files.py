@@ -36,7 +36,13 @@ def test_gpu_matches_oracle_on_fixture(name):
         for batch in ((8192,) if big else (8192, 1000)):
             res = G.gpu_decode(s.number_of_rows, cols, streams, compression=f.compression_name, block_size=f.block_size, batch_size=batch,
                                writer_timezone=s.writer_timezone)
+            fails = A.REFERENCE_FAILS.get(name, ())
+            if fails:
+                # several columns fail (in their first batch): the result names the first of them, as the reader would (arrow_reader.rs:333-346)
+                G.assert_stripe_parity(res, cols, streams, s.number_of_rows, batch, compression=f.compression_name, block_size=f.block_size, what=(name, si, batch))
             for ci, c in enumerate(cols):
+                if c["name"] in fails:
+                    continue
                 G.assert_column_parity(res, ci, c, streams, s.number_of_rows, batch, compression=f.compression_name, block_size=f.block_size,
                                        what=(name, si, c["name"], batch), writer_timezone=s.writer_timezone)
             res.free()

@@ -10,7 +10,10 @@ import orcfile
 import oracle_lib as O
 
 
-def decode_column(f, col_id, typ, batch_size):
+REFERENCE_FAILS = A.REFERENCE_FAILS
+
+
+def decode_column(f, col_id, typ, batch_size, expect_failure=False):
     chunks = []
     for s in f.stripes:
         col = f.oracle_column(s, col_id)
@@ -19,6 +22,10 @@ def decode_column(f, col_id, typ, batch_size):
         while left > 0:
             n = min(batch_size, left)
             b = col.next_batch(n)
+            if expect_failure:
+                assert b["status"] in (O.OUT_OF_SPEC, O.IO_ERROR), (col_id, b["status"])
+                col.close()
+                return None
             assert b["status"] == O.OK, (col_id, b["status"])
             chunks.append(A.to_arrow(typ.kind, b, typ.precision, typ.scale))
             left -= n
@@ -37,6 +44,9 @@ def test_oracle_matches_golden(name):
     checked = 0
     for cname, cid, typ in f.flat_columns():
         for batch_size in ((8192,) if big else (8192, 1000, 7)):
+            if cname in REFERENCE_FAILS.get(name, ()):
+                assert decode_column(f, cid, typ, batch_size, expect_failure=True) is None
+                continue
             chunks = decode_column(f, cid, typ, batch_size)
             want = expected.column(cname)
             if chunks:
