@@ -288,6 +288,49 @@ def cpu_baseline(stripes, comp, budget_s=12.0):
     return out
 
 
+class CpuBaselineHelper:
+    """The CPU baseline forks worker processes, which this process may only do before it initialises the GPU -- but timed in front
+    of the GPU work it made rank 0 late at the rendezvous of an N-rank job (the other ranks waited for it at the store).  So: a
+    helper process is forked HERE, early (it shares the generated stripes copy-on-write and never touches the GPU), sleeps on a
+    pipe, and times the baseline when rank 0 asks for it -- behind the timed region, while the other ranks wait at the last barrier."""
+
+    def __init__(self, stripes, comp):
+        self._go_r, self._go_w = os.pipe()
+        self._out_r, self._out_w = os.pipe()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        self.pid = os.fork()
+        if self.pid == 0:
+            code = 1
+            try:
+                os.close(self._go_w)
+                os.close(self._out_r)
+                if os.read(self._go_r, 1) == b"g":
+                    data = json.dumps(cpu_baseline(stripes, comp)).encode()
+                    while data:
+                        data = data[os.write(self._out_w, data):]
+                code = 0
+            finally:
+                os._exit(code)
+        os.close(self._go_r)
+        os.close(self._out_w)
+
+    def run(self):
+        os.write(self._go_w, b"g")
+        os.close(self._go_w)
+        chunks = []
+        while True:
+            b = os.read(self._out_r, 1 << 16)
+            if not b:
+                break
+            chunks.append(b)
+        os.close(self._out_r)
+        _, status = os.waitpid(self.pid, 0)
+        if status != 0 or not chunks:
+            raise RuntimeError("the CPU baseline helper failed (exit status %d)" % status)
+        return json.loads(b"".join(chunks).decode())
+
+
 class _DevBytes:
     """A device range as torch sees it (__cuda_array_interface__): the checker's only view of the result buffers."""
 
@@ -459,10 +502,16 @@ def pmc_traffic(workload, comp, kernel_key, algo_bytes_per_launch):
     another table size: the kernel's measured bytes per ALGORITHMIC byte are applied to this run's algorithmic bytes per launch.
     FETCH_SIZE is taken raw (the gfx950 x2 correction applies to wide coalesced reads only: both figures are in the file)."""
     import glob
+    from orc_rust_amd import build as _b
     tag = {"lineitem": "lineitem_" + str(comp), "c3": "c3_" + str(comp), "c2": "c2"}.get(workload)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
-            w = json.load(open(f))["workloads"].get(tag)
+            doc = json.load(open(f))
+            if doc.get("source_digest") != _b.source_digest():
+                # the passes measured other kernels than the ones running now: no figure is better than a stale one
+                return None, "%s was collected for sources %s, these are %s: collect the PMC passes again (profiles/collect_r06.sh)" % (
+                    os.path.basename(f), doc.get("source_digest"), _b.source_digest())
+            w = doc["workloads"].get(tag)
             k = w["kernels"][PMC_NAMES[kernel_key]]
             per_algo = (k["FETCH_KB_run"] + k["WRITE_KB_run"]) * 1024.0 / w["decode_calls_in_run"] / w["algorithmic_bytes_per_step"]
             return int(per_algo * algo_bytes_per_launch), "%s: %s, (FETCH_SIZE raw + WRITE_SIZE) per algorithmic byte of the pass x this run's algorithmic bytes per launch" % (
@@ -516,6 +565,117 @@ def lanes_of(lane_acc):
     return out
 
 
+def bench_demo12(args):
+    """The reference's OWN benchmark workload (benches/arrow_reader.rs:42-67): the full read of tests/basic/data/demo-12-zlib.orc
+    -- 1 920 800 rows, 9 columns, ONE stripe, ZLIB -- through the reader front (orcgpu_reader_open_file / next_batch: file bytes ->
+    staged -> decoded -> copied back -> Arrow C Data batches of 8192 rows, every batch released at once).  A step = one whole read,
+    open included.  The worst case for this design: a 46 KB file whose DEFLATE chunks are a handful of serial chains -- latency, not
+    throughput.  Beside it: Apache ORC C++ through PyArrow (311 ms on the survey container) and the CPU oracle on one core."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    path = os.path.join(ROOT, "tests", "golden", "data", "demo-12-zlib.orc")
+    if not os.path.isdir("/usr/share/zoneinfo") and "TZDIR" not in os.environ:
+        import tzdata
+        os.environ["TZDIR"] = os.path.join(os.path.dirname(tzdata.__file__), "zoneinfo")
+    import pyarrow as pa
+    import pyarrow.orc as orc
+    table = orc.ORCFile(path).read()
+    rows, arrow_bytes, file_bytes = table.num_rows, table.nbytes, os.path.getsize(path)
+    cpu = None
+    if not args.no_cpu:
+        best_pa = min(_timed(lambda: orc.ORCFile(path).read()) for _ in range(5))
+        import orcfile
+        import oracle_lib as O
+
+        def oracle_read():
+            f = orcfile.OrcFile(path)
+            for s_ in f.stripes:
+                for _, cid, _t in f.flat_columns():
+                    col = f.oracle_column(s_, cid)
+                    left = s_.number_of_rows
+                    while left > 0:
+                        b = col.next_batch(min(8192, left))
+                        assert b["status"] == O.OK
+                        left -= 8192
+                    col.close()
+        best_or = min(_timed(oracle_read) for _ in range(2))
+        cpu = {"value": round(arrow_bytes / best_or / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port", "ms": round(best_or * 1e3, 1),
+               "sample": "the whole file, every flat column batch by batch (8192), oracle/liborc_oracle.so, best of 2",
+               "pyarrow_orc_cpp": {"ms": round(best_pa * 1e3, 1), "GBps": round(arrow_bytes / best_pa / 1e9, 4), "cores": 1,
+                                   "what": "pyarrow.orc.ORCFile(path).read() = Apache ORC C++, best of 5 on this host (BASELINE.md: 311 ms on the survey container)"}}
+    import torch
+    torch.cuda.set_device(0)
+    from orc_rust_amd import ArrowReaderBuilder, capi
+    ctx = capi.Context(0)
+    L = ctx.L
+    # parity first: the reader's batches are the PyArrow table
+    batches = list(ArrowReaderBuilder.try_new(path, ctx).build())
+    got = pa.Table.from_batches(batches)
+    assert got.num_rows == rows
+    for name in table.schema.names:
+        g, w = got.column(name), table.column(name)
+        assert g.equals(w.cast(g.type) if g.type != w.type else w), name
+    del batches, got
+
+    class ArrowArray(C.Structure):
+        _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64), ("n_children", C.c_int64),
+                    ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.CFUNCTYPE(None, C.c_void_p)), ("private_data", C.c_void_p)]
+
+    class ArrowSchema(C.Structure):
+        _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_void_p), ("flags", C.c_int64), ("n_children", C.c_int64),
+                    ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.CFUNCTYPE(None, C.c_void_p)), ("private_data", C.c_void_p)]
+
+    def read_once(prefetch):
+        h = C.c_void_p()
+        t0 = time.perf_counter()
+        assert L.orcgpu_reader_open_file(ctx.h, path.encode(), C.byref(h)) == 0
+        L.orcgpu_reader_set_prefetch(h, prefetch)
+        n = 0
+        while True:
+            a, sc = ArrowArray(), ArrowSchema()
+            rc = L.orcgpu_reader_next_batch(h, C.byref(a), C.byref(sc))
+            if rc == 110:  # ORCGPU_END_OF_FILE
+                break
+            assert rc == 0, rc
+            n += a.length
+            a.release(C.addressof(a))
+            sc.release(C.addressof(sc))
+        dt = time.perf_counter() - t0
+        L.orcgpu_reader_close(h)
+        assert n == rows
+        return dt
+    modes = {}
+    for prefetch in (0, 2):
+        for _ in range(max(1, args.warmup)):
+            read_once(prefetch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            read_once(prefetch)
+        modes[prefetch] = (time.perf_counter() - t0) / args.steps
+    dt = modes[0]
+    algo = file_bytes + arrow_bytes
+    out = {"metric": "decoded GB/s + Mrows/s into Arrow", "value": round(arrow_bytes / dt / 1e9, 3), "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64/u8", "data": "the reference's fixture file",
+           "config": {"workload": "the reference's own benchmark (benches/arrow_reader.rs:42-67): full read of demo-12-zlib.orc, %d rows, 9 columns, 1 stripe, ZLIB, "
+                                  "through orcgpu_reader_* (file -> Arrow C Data batches in pinned host memory: PCIe both ways INCLUDED)" % rows,
+                      "rows": rows, "stripes": 1, "batch_size": 8192, "compression": "zlib", "parallelism": "one reader, serial (prefetch 0)"},
+           "mrows_per_s": round(rows / dt / 1e6, 1), "file_bytes": file_bytes, "arrow_bytes_out": arrow_bytes,
+           "ms_per_read_with_read_ahead": round(modes[2] * 1e3, 4),
+           "roofline": {"bound": "hbm", "kernel": None, "achieved": round(algo / dt / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(algo / dt / 1e9 / HBM_PEAK_GBPS, 6),
+                        "traffic": None, "note": "a whole-file read, host to host: latency of one stripe's launch chain and its DEFLATE chains, not a throughput figure"}}
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
+def _timed(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -525,7 +685,7 @@ def main():
                     help="c3: stage the PRESENT and DATA streams with their ROW_INDEX positions (BASELINE's C3 is measured without)")
     ap.add_argument("--no-row-index", action="store_true",
                     help="c2-adv / c2-rowgroup: stage the stream without its ROW_INDEX positions (a file written without indexes)")
-    ap.add_argument("--workload", default="lineitem", choices=["lineitem", "c2", "c2-direct", "c2-delta", "c2-arange", "c2-adv", "c2-rowgroup", "c3", "c5"],
+    ap.add_argument("--workload", default="lineitem", choices=["lineitem", "c2", "c2-direct", "c2-delta", "c2-arange", "c2-adv", "c2-rowgroup", "c3", "c5", "demo12"],
                     help="lineitem (default) = the headline; the others are BASELINE.md's remaining configs, recorded under profiles/")
     ap.add_argument("--compression", default=None, choices=[None, "none", "zstd", "snappy", "lz4", "zlib"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (weak) / of the table (strong); 0 = the config's own size")
@@ -538,6 +698,10 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="profiling runs: skip the pipelined host-to-host measurement behind the timed region")
     args = ap.parse_args()
 
+    if args.workload == "demo12":
+        if args.gpus != 1:
+            raise SystemExit("--workload demo12 is a one-file, one-stripe read: one GPU")
+        return bench_demo12(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -551,11 +715,10 @@ def main():
     # this process initialises the GPU.
     stripes, comp, label, shard_desc, plan = build_workload(args, rank, world)
     cpu = None
+    cpu_helper = None
     if rank == 0 and not args.no_cpu and stripes:
-        # rank 0 only, on ITS share of the workload (N > 1: the other ranks wait for it at the rendezvous, their cores are idle)
-        cpu = cpu_baseline(stripes, comp)
-        if world > 1:
-            cpu["sample"] += "; rank 0's share of the %d-rank job" % world
+        # rank 0 only, on ITS share of the workload; timed behind the GPU work (CpuBaselineHelper: forked now, before the GPU is touched)
+        cpu_helper = CpuBaselineHelper(stripes, comp)
     if world > 1:
         # one process per GPU on one host: every rank's staging helpers get the rank's share of the usable cores
         os.environ.setdefault("ORCGPU_STAGE_THREADS", str(max(0, min(6, host_workers(world) - 1))))
@@ -725,6 +888,11 @@ def main():
     if per_rank is not None:
         out["per_rank"] = per_rank
     if rank == 0:
+        if cpu_helper is not None:
+            # (N > 1: the other ranks are at the barrier below meanwhile, their cores idle -- the timed region is long over)
+            cpu = cpu_helper.run()
+            if world > 1:
+                cpu["sample"] += "; rank 0's share of the %d-rank job" % world
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -20,6 +20,18 @@ def _sources():
     return out
 
 
+def source_digest():
+    """sha256 over the library's sources (names and bytes): what a PMC pass was collected for -- bench.py prices `roofline.traffic`
+    with the committed passes only while the sources are still the ones they measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(_sources()):
+        h.update(os.path.relpath(f, os.path.dirname(HERE)).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _fresh(srcs):
     return os.path.exists(SO) and all(os.path.getmtime(s) <= os.path.getmtime(SO) for s in srcs)
 

@@ -28,10 +28,6 @@
 #define ORC_EXPAND_WAVES 4
 #endif
 
-// rle2_expand_short_kernel: blocks per wavefront whose bytes are staged in LDS, and the bytes behind them staged too (the window
-// of a header that starts in the group's last bytes, the payload of a short run that ends behind them)
-#define RLE_STAGE_BLKS 8u
-#define RLE_STAGE_TAIL 96u
 struct WaveLds {
   uint32_t start[65];
   uint32_t cstart[65];  // narrow keys: first 8-value chunk of every run slot (see the chunk pass of expand_group)
@@ -114,8 +110,7 @@ __device__ __forceinline__ void report(RleJob* j, uint64_t needed, uint64_t oi, 
 }
 
 // One value of a random-access run (SHORT_REPEAT, DIRECT, fixed DELTA, v1 run, byte run / literal).
-// `ld8(byte offset)`: the 8 stream bytes at that offset from the run's payload, as loaded (little endian) -- from memory, or from
-// the wavefront's LDS copy of its blocks (rle2_expand_short_kernel).
+// `ld8(byte offset)`: the 8 stream bytes at that offset from the run's payload, as loaded (little endian).
 template <typename LD8>
 __device__ __forceinline__ int64_t decode_b1(uint32_t type, uint32_t w, int64_t base, int64_t dlt, LD8 ld8, uint32_t idx,
                                              bool is_signed, int nbits, bool& bad) {
@@ -156,9 +151,9 @@ __device__ __forceinline__ void direct_pair_load(const uint8_t* pp, uint32_t i0,
   }
 }
 
-template <int CODEC, int OB, int NB = OB * 8, bool STAGED = false>
+template <int CODEC, int OB, int NB = OB * 8>
 __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, const uint64_t* scalars, uint32_t lg, WaveLds& L,
-                                             uint32_t lane, uint8_t* stage PROF_PARM) {
+                                             uint32_t lane PROF_PARM) {
   const uint8_t* data = as_global(j->data);
   void* out = as_global(j->out);
   const uint64_t len = scalars[j->len_idx];
@@ -170,24 +165,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
   const uint32_t G = j->group_size;
   const uint32_t eof_code = CODEC == CODEC_BYTE ? ORC_E_IO : ORC_E_OUT_OF_SPEC;
 
-  // STAGED (rle2_expand_short_kernel: groups of at most RLE_STAGE_BLKS blocks): the group's stream bytes [s0, s1) are copied to LDS
-  // once, with coalesced loads; run headers and the payloads of short runs are then read from there -- a header of a short-run
-  // stream costs an LDS access (~0.1 us) instead of a dependent trip to L2 (~1 us), and a block of such a stream holds ~200 of them
-  const uint64_t s0 = STAGED ? (uint64_t)lg * G * RLE_BLK : 0, s1 = STAGED ? (s0 + (uint64_t)G * RLE_BLK + RLE_STAGE_TAIL < len + 16 ? s0 + (uint64_t)G * RLE_BLK + RLE_STAGE_TAIL : len + 16) : 0;
-  if (STAGED) {
-    for (uint64_t o = s0 + lane * 16; o < s1; o += 1024) {
-      uint64_t v[2];
-      __builtin_memcpy(v, data + o, 16);  // (the last piece may reach 15 bytes behind s1 <= len + 16: inside the ORC_PAD bytes of slack every stream carries)
-      __builtin_memcpy(stage + (o - s0), v, 16);
-    }
-    wave_sync();
-  }
-  auto staged24 = [&](uint64_t p) -> bool { return STAGED && p >= s0 && p + 24 <= s1; };
-  // 8 stream bytes at `off`
-  auto ld8_at = [&](uint64_t off) -> uint64_t {
-    if (STAGED && off >= s0 && off + 8 <= s1) return ld_u64(stage + (off - s0));
-    return ld_u64(data + off);
-  };
+  auto ld8_at = [&](uint64_t off) -> uint64_t { return ld_u64(data + off); };  // 8 stream bytes at `off`
   PROF_MARK(8);
   uint32_t lb = lg * G + lane;
   bool active = false, tail_owner = false;
@@ -225,7 +203,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
         L.soi[lane * K + k] = (uint32_t)o;
         if (CODEC == CODEC_RLE2) {
           // SHORT_REPEAT / DIRECT from the header's two bytes (rle2_hop2); whatever else there is takes the full parse
-          const uint32_t hw = staged24(p) ? (uint32_t)stage[p - s0] | ((uint32_t)stage[p - s0 + 1] << 8) : (uint32_t)data[p] | ((uint32_t)data[p + 1] << 8);
+          const uint32_t hw = (uint32_t)data[p] | ((uint32_t)data[p + 1] << 8);  // (the second byte may be the first of the stream's slack: ORC_PAD)
           uint32_t fsz, fn;
           if (rle2_hop2(hw & 0xff, hw >> 8, nbits, len - p, fsz, fn)) {
             p += fsz;
@@ -234,8 +212,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
           }
         }
         RunHdr hh;
-        if (staged24(p)) run_parse<CODEC, false>(stage + (p - s0), len - p, is_signed, nbits, hh);
-        else run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, hh);
+        run_parse<CODEC, false>(data + p, len - p, is_signed, nbits, hh);
         if (hh.err) clean = false;
         p += hh.size;
         o += hh.n;
@@ -258,8 +235,7 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
     uint32_t cnt = 0, chunks = 0;
     if (has) {
       const uint64_t soi = L.soi[lane];
-      if (staged24(sp)) run_parse<CODEC, true>(stage + (sp - s0), len - sp, is_signed, nbits, h);
-      else run_parse<CODEC, true>(data + sp, len - sp, is_signed, nbits, h);
+      run_parse<CODEC, true>(data + sp, len - sp, is_signed, nbits, h);
       if (K == 1) {
         if (h.err) clean = false;
         pos = sp + h.size;
@@ -436,6 +412,68 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
             int64_t pr[2] = {va[u], vb[u]};
             __builtin_memcpy((int64_t*)out + o0 + i0 + u * 128 + 2 * lane, pr, 16);
           }
+          if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[cur] - 1);
+          q0 += 512;
+          continue;
+        }
+        if (OB == 4 && !narrow && rend - q0 >= 512 && (uint64_t)L.oidx[cur] + (q0 - L.start[cur]) + 512 <= needed) {
+          // 512 int32 values of ONE run (dates, decimal scales, 32-bit integers): every lane produces FOUR consecutive values per
+          // step -- 24 payload bytes in, one 16-byte store out, 1 KiB per wave store -- instead of four 4-byte stores 256 bytes apart
+          const uint32_t m = L.meta[cur];
+          const uint32_t type = m & 0xff, w = (m >> 8) & 0xff;
+          const int64_t base = L.base[cur], dlt = L.delta[cur];
+          const uint64_t o0 = L.oidx[cur];
+          const uint8_t* pp = data + L.pay[cur];
+          const uint32_t i0 = q0 - L.start[cur];
+          bool bad = false;
+          int32_t v4[2][4];
+          if (type == RT_DIRECT) {
+            uint64_t pf[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              const uint64_t bit = (uint64_t)(i0 + u * 256 + 4 * lane) * w;
+              const uint8_t* q = pp + (bit >> 3);
+              pf[u][0] = ld_u64(q);
+              pf[u][1] = ld_u64(q + 8);
+              pf[u][2] = ld_u64(q + 16);  // (4 x 32 bits behind up to 7: 17 bytes at most; the rest is slack -- ORC_PAD)
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              const uint64_t hi = __builtin_bswap64(pf[u][0]), mid = __builtin_bswap64(pf[u][1]), lo = __builtin_bswap64(pf[u][2]);
+              const uint32_t sh = (uint32_t)(((uint64_t)(i0 + u * 256 + 4 * lane) * w) & 7);
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const uint32_t pos = sh + k * w;  // < 7 + 96 + 1
+                const uint64_t a = pos < 64 ? hi : mid, b = pos < 64 ? mid : lo;
+                const uint32_t r = pos & 63;
+                const uint64_t x = r ? (a << r) | (b >> (64 - r)) : a;
+                const uint64_t uval = x >> (64 - w);
+                v4[u][k] = (int32_t)(is_signed ? zigzag_n(uval, nbits) : trunc_n((int64_t)uval, nbits));
+              }
+            }
+          } else if (type == RT_DELTA) {
+            // fixed delta: an arithmetic progression, monotonic -- the segment's last value decides whether a step left N's range
+            const int64_t step = dlt;
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+              for (int k = 0; k < 4; k++) v4[u][k] = (int32_t)((uint64_t)base + (uint64_t)(i0 + u * 256 + 4 * lane + k) * (uint64_t)step);
+            const __int128 last = (__int128)base + (__int128)(i0 + 511) * (__int128)step;
+            bad = last > (__int128)INT32_MAX || last < (__int128)INT32_MIN;
+          } else if (type == RT_SR || type == RT_B_RUN) {
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+              for (int k = 0; k < 4; k++) v4[u][k] = (int32_t)base;
+          } else {
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                v4[u][k] = (int32_t)decode_b1(type, w, base, dlt, [&](uint32_t o) { return ld_u64(pp + o); }, i0 + u * 256 + 4 * lane + k, is_signed, nbits, bad);
+          }
+#pragma unroll
+          for (int u = 0; u < 2; u++) __builtin_memcpy((int32_t*)out + o0 + i0 + u * 256 + 4 * lane, v4[u], 16);
           if (bad) report(j, needed, o0, ORC_E_OUT_OF_SPEC, L.pay[cur] - 1);
           q0 += 512;
           continue;
@@ -669,54 +707,46 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
   if (tail_owner && clean && pos >= len) report(j, needed, oi, eof_code | ORC_E_EOF, len);
 }
 
-template <int CODEC, bool STAGED = false>
-__device__ __forceinline__ void expand_entry(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars, uint32_t group_begin, uint32_t total_groups) {
+template <int CODEC>
+__device__ __forceinline__ void expand_entry(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars, uint32_t total_groups) {
   __shared__ WaveLds lds[4];
-  __shared__ __attribute__((aligned(16))) uint8_t stage_all[STAGED ? 4 : 1][STAGED ? RLE_STAGE_BLKS * RLE_BLK + RLE_STAGE_TAIL + 16 : 16];
   uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint32_t g = group_begin + blockIdx.x * 4 + wv;
+  uint32_t g = blockIdx.x * 4 + wv;
   if (g >= total_groups) return;
   PROF_BEGIN();
   RleJob* j = &jobs[group_job[g]];
   uint32_t lg = g - j->group0;
   if (lg >= j->ngroups) return;
-  uint8_t* stage = stage_all[STAGED ? wv : 0];
   PROF_MARK(9);
   if (CODEC == CODEC_BYTE) {
-    expand_group<CODEC, 1, 8, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG);
+    expand_group<CODEC, 1>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
   } else {
     // wave-uniform dispatch on the value width: the bodies are specialised at compile time
     switch (j->out_bytes) {
-      case 8: expand_group<CODEC, 8, 64, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG); break;
+      case 8: expand_group<CODEC, 8>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;
       case 4:
-        if (j->nbits == 64) expand_group<CODEC, 4, 64, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG);
-        else expand_group<CODEC, 4, 32, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG);
+        if (j->nbits == 64) expand_group<CODEC, 4, 64>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
+        else expand_group<CODEC, 4>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
         break;
       case 2:
-        if (j->nbits == 64) expand_group<CODEC, 2, 64, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG);
-        else expand_group<CODEC, 2, 16, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG);
+        if (j->nbits == 64) expand_group<CODEC, 2, 64>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
+        else expand_group<CODEC, 2>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
         break;
-      default: expand_group<CODEC, 1, 64, STAGED>(j, blk, scalars, lg, lds[wv], lane, stage PROF_ARG); break;  // (one-byte dictionary keys)
+      default: expand_group<CODEC, 1, 64>(j, blk, scalars, lg, lds[wv], lane PROF_ARG); break;  // (one-byte dictionary keys)
     }
   }
   PROF_END();
 }
 
-// Groups [group_begin, total_groups) of the class's group table: the host puts the jobs whose groups are staged (short-run streams:
-// group_size <= RLE_STAGE_BLKS) behind the others, each kind gets its own launch.
 extern "C" __global__ void __launch_bounds__(256, ORC_EXPAND_WAVES) rle2_expand_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,
-                                                                      uint32_t group_begin, uint32_t total_groups) {
-  expand_entry<CODEC_RLE2>(jobs, group_job, blk, scalars, group_begin, total_groups);
-}
-extern "C" __global__ void __launch_bounds__(256, 3) rle2_expand_short_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,
-                                                                      uint32_t group_begin, uint32_t total_groups) {
-  expand_entry<CODEC_RLE2, true>(jobs, group_job, blk, scalars, group_begin, total_groups);
+                                                                      uint32_t total_groups) {
+  expand_entry<CODEC_RLE2>(jobs, group_job, blk, scalars, total_groups);
 }
 extern "C" __global__ void __launch_bounds__(256) rle1_expand_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,
-                                                                      uint32_t group_begin, uint32_t total_groups) {
-  expand_entry<CODEC_RLE1>(jobs, group_job, blk, scalars, group_begin, total_groups);
+                                                                      uint32_t total_groups) {
+  expand_entry<CODEC_RLE1>(jobs, group_job, blk, scalars, total_groups);
 }
 extern "C" __global__ void __launch_bounds__(256) byte_expand_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,
-                                                                      uint32_t group_begin, uint32_t total_groups) {
-  expand_entry<CODEC_BYTE>(jobs, group_job, blk, scalars, group_begin, total_groups);
+                                                                      uint32_t total_groups) {
+  expand_entry<CODEC_BYTE>(jobs, group_job, blk, scalars, total_groups);
 }

@@ -388,10 +388,13 @@ __device__ __forceinline__ bool rle_hopeless(const RleJob* j, uint64_t len) {
 }
 // mode 0: guess; 1: relaxation round; 2: verify only; 3: strong blocks fill their pass-through blocks.
 // Every wavefront covers 64 consecutive blocks of ONE stream (block ranges are RLE_TILE aligned).
-extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
-                                                                   uint32_t total_blocks, int mode) {
-  __shared__ unsigned long long bitmaps[4][64][8];
-  uint32_t b = blockIdx.x * 256u + threadIdx.x;
+// (Workgroups of ONE wavefront -- the wavefronts never meet --: a lane's walk starts while the other column lane's execution kernel,
+// single-wavefront workgroups that fill every CU's LDS, still runs; a 256-thread workgroup then waits until four slots and 16 KiB
+// of LDS are free on one CU at once, which that kernel never leaves: round 5's first walk launch spent 1.4 - 4.9 ms in the queue.)
+extern "C" __global__ void __launch_bounds__(64) rle_walk_kernel(RleJob* jobs, int njobs, RleBlocks blk, const uint64_t* scalars,
+                                                                  uint32_t total_blocks, int mode) {
+  __shared__ unsigned long long bitmaps[1][64][8];
+  uint32_t b = blockIdx.x * 64u + threadIdx.x;
   uint32_t lane = threadIdx.x & 63;
   uint32_t bw = b - lane;  // first block of this wavefront
   if (bw >= total_blocks) return;
@@ -463,7 +466,7 @@ extern "C" __global__ void __launch_bounds__(256) rle_walk_kernel(RleJob* jobs, 
     if (mode == 0) PROF_MARK(0);
     if (__ballot(need)) {
       uint32_t cand;
-      unsigned long long(*bm)[8] = bitmaps[threadIdx.x >> 6];
+      unsigned long long(*bm)[8] = bitmaps[0];
       if (j->codec == CODEC_RLE2) cand = wave_find_candidates<CODEC_RLE2>(data, len, lb, need, j->is_signed, j->nbits, bm, lane PROF_ARG);
       else if (j->codec == CODEC_RLE1) cand = wave_find_candidates<CODEC_RLE1>(data, len, lb, need, j->is_signed, j->nbits, bm, lane PROF_ARG);
       else cand = wave_find_candidates<CODEC_BYTE>(data, len, lb, need, false, 8, bm, lane PROF_ARG);
