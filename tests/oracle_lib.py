@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(ROOT, "oracle", "liborc_oracle.so")
+# ORC_ORACLE_SO: another build of the same sources -- oracle/liborc_oracle_asan.so, the AddressSanitizer / UBSan build that
+# tests/test_host_sanitized.py runs the known-answer and codec tests against (LD_PRELOAD=libasan.so)
+_SO = os.environ.get("ORC_ORACLE_SO") or os.path.join(ROOT, "oracle", "liborc_oracle.so")
 
 OK, IO_ERROR, OUT_OF_SPEC, VARINT_TOO_LARGE, DECODE_TIMESTAMP, OFFSET_OVERFLOW = 0, 1, 2, 3, 4, 5
 MISMATCHED_SCHEMA, UNSUPPORTED, ARROW, BUILD_DECODER, UNEXPECTED = 6, 7, 8, 9, 10
@@ -20,7 +22,7 @@ COMP = {"none": 0, "zlib": 1, "snappy": 2, "lzo": 3, "lz4": 4, "zstd": 5}
 def build():
     srcs = [os.path.join(ROOT, "oracle", f) for f in ("oo_codecs.c", "oo_encoding.c", "oo_column.c", "oo_encode.c", "orc_oracle.h")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liborc_oracle.so"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), os.path.basename(_SO)])
     return _SO
 
 

@@ -1,0 +1,168 @@
+"""Sanitizers where they can run (GPU AddressSanitizer and XNACK are not available on the pool): the HOST layer of the product --
+the protobuf wire reader, PostScript / Footer / StripeFooter / RowIndex parsing, type-tree validation, row-index entry splitting,
+row-group statistics and Bloom filters, RowSelection stepping, the column shard's deal, the TZif reader -- is plain C++ that needs
+no device.  tests/hostcheck/hostcheck.cpp compiles exactly the text liborcgpu.so is built from (orc_rust_amd/csrc/orcgpu_meta.inc,
+orcgpu_predicate.inc, orcgpu_selection.inc, orcgpu_tz.inc) with g++ -fsanitize=address,undefined; here it is fed every golden
+file, the reference's odd and corrupt containers, and thousands of seeded truncations / bit flips / byte overwrites of tails and
+stripe footers: the parsers must RETURN (a status or a parse), never trip a sanitizer.  The oracle's known-answer and codec tests
+run once more against its own ASan / UBSan build (oracle/Makefile: liborc_oracle_asan.so).  No GPU anywhere in this file."""
+import json
+import os
+import random
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+import arrow_util as A
+import orcfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:exitcode=99", UBSAN_OPTIONS="halt_on_error=1:exitcode=98:print_stacktrace=1")
+
+
+@pytest.fixture(scope="session")
+def hostcheck(tmp_path_factory):
+    d = tmp_path_factory.mktemp("hostcheck")
+    objs = []
+    for f in ("oo_codecs", "oo_encoding", "oo_column", "oo_encode"):
+        o = str(d / (f + ".o"))
+        subprocess.check_call(["gcc", "-std=gnu11"] + SAN + ["-c", os.path.join(ROOT, "oracle", f + ".c"), "-o", o])
+        objs.append(o)
+    exe = str(d / "hostcheck")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall"] + SAN + ["-o", exe, os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")] + objs)
+    return exe
+
+
+def run(exe, *args):
+    p = subprocess.run([exe] + [str(a) for a in args], env=ENV, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, "sanitizer report or crash (exit %d):\n%s" % (p.returncode, p.stderr.decode()[-4000:])
+    return json.loads(p.stdout.decode().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", A.golden_files())
+def test_walk_of_every_golden_file_agrees_with_the_test_parser(hostcheck, name):
+    """The product's host parsers and the tests' own Python container reader (tests/orcfile.py) see the same file."""
+    out = run(hostcheck, "walk", A.data_path(name))
+    f = orcfile.OrcFile(A.data_path(name))
+    assert out["status"] == 0, out
+    assert out["rows"] == f.number_of_rows and out["stripes"] == len(f.stripes) and out["types"] == len(f.types)
+    assert out["streams"] == sum(len(s.stream_list) for s in f.stripes)
+
+
+@pytest.mark.parametrize("name,status", [("zero.orc", 2), ("version1999.orc", 0), ("TestOrcFile.testWithoutCompressionBlockSize.orc", 0),
+                                         ("TestOrcFile.testTimestamp.orc", 0), ("missing_blob_stream_in_string_dict.orc", 0),
+                                         ("missing_length_stream_in_string_dict.orc", 0), ("negative_dict_entry_lengths.orc", 0),
+                                         ("stripe_footer_bad_column_encodings.orc", None)])
+def test_walk_of_the_odd_and_corrupt_containers(hostcheck, name, status):
+    """tests/golden/edge/: what is wrong with the three dictionary files lies in their STREAMS (the container parses); the bad
+    stripe footer must come back as a status."""
+    out = run(hostcheck, "walk", os.path.join(A.GOLDEN, "edge", name))
+    if status is None:
+        assert out["status"] != 0
+    else:
+        assert out["status"] == status, out
+
+
+FUZZ = ["test.orc", "alltypes.none.orc", "alltypes.zlib.orc", "alltypes.snappy.orc", "alltypes.zstd.orc", "alltypes.lz4.orc", "alltypes.lzo.orc",
+        "TestOrcFile.testSeek.orc", "TestOrcFile.test1.orc", "TestVectorOrcFile.testZstd.0.12.orc", "nulls-at-end-snappy.orc", "decimal.orc",
+        "TestOrcFile.testUnionAndTimestamp.orc", "orc_index_int_string.orc", "bloom_filter.orc", "over1k_bloom.orc", "complextypes_iceberg.orc",
+        "TestOrcFile.emptyFile.orc", "orc_no_format.orc", "demo-11-zlib.orc"]
+
+
+@pytest.mark.parametrize("name", FUZZ)
+def test_container_fuzz_under_asan_and_ubsan(hostcheck, name):
+    """Truncations, bit flips and byte overwrites in the last 16 KiB and in every stripe footer (half of the hits there): every
+    mutated file is walked like orcgpu_reader_open_* + every stripe's footer and ROW_INDEX / BLOOM_FILTER streams.  Whatever comes
+    back is a status the C ABI knows; most mutations must be NOTICED (a status), a good part must still parse."""
+    n = 150 if name.startswith("demo") else 600
+    out = run(hostcheck, "fuzz", A.data_path(name), hash(name) & 0xffff, n)
+    assert out["clean_status"] == 0
+    oc = {int(k): v for k, v in out["outcomes"].items()}
+    assert sum(oc.values()) == n and set(oc) <= {0, 1, 2, 9}, oc
+    assert oc.get(2, 0) + oc.get(1, 0) + oc.get(9, 0) > 0, oc
+
+
+def test_crafted_type_trees(hostcheck, tmp_path):
+    """The advisor's case (round 5): a type list that is no preorder tree -- a type naming itself, two parents, the DAG
+    k -> [k + 1, k + 1] that cost 2^depth visits -- is OutOfSpec after ONE pass over the list; a deep but well-formed chain parses."""
+    def varint(v):
+        out = bytearray()
+        while True:
+            b = v & 0x7f
+            v >>= 7
+            out.append(b | (0x80 if v else 0))
+            if not v:
+                return bytes(out)
+
+    def field(num, payload):
+        return varint(num << 3 | 2) + varint(len(payload)) + payload
+
+    def typ(kind, subtypes, names=()):
+        body = varint(1 << 3) + varint(kind)
+        for s_ in subtypes:
+            body += varint(2 << 3) + varint(s_)
+        for nm in names:
+            body += field(3, nm if isinstance(nm, bytes) else nm.encode())
+        return field(4, body)
+
+    def file_with(types):
+        footer = varint(1 << 3) + varint(3) + varint(2 << 3) + varint(3) + b"".join(types) + varint(6 << 3) + varint(0)
+        ps = varint(1 << 3) + varint(len(footer)) + varint(2 << 3) + varint(0) + varint(5 << 3) + varint(0) + field(8000, b"ORC")
+        return b"ORC" + footer + ps + bytes([len(ps)])
+
+    cases = {
+        "ok": (file_with([typ(12, [1, 2], ["a", "b"]), typ(4, []), typ(7, [])]), 0),
+        "chain": (file_with([typ(12, [1], ["a"])] + [typ(12, [k + 1], ["x"]) for k in range(1, 300)] + [typ(4, [])]), 0),
+        "self": (file_with([typ(12, [1], ["a"]), typ(12, [1, 1], ["x", "y"])]), 2),
+        "two_parents": (file_with([typ(12, [1, 1], ["a", "b"]), typ(4, [])]), 2),
+        "dag": (file_with([typ(12, [1], ["a"])] + [typ(12, [k + 1, k + 1], ["x", "y"]) for k in range(1, 60)] + [typ(4, [])]), 2),
+        "outside": (file_with([typ(12, [5], ["a"]), typ(4, [])]), 2),
+        "back": (file_with([typ(12, [1], ["a"]), typ(12, [0], ["up"])]), 2),
+        "name_not_utf8": (file_with([typ(12, [1], [b"\xe5\x80"]), typ(4, [])]), 2),
+    }
+    for tag, (data, want) in cases.items():
+        path = tmp_path / (tag + ".orc")
+        path.write_bytes(data)
+        assert run(hostcheck, "walk", path)["status"] == want, tag
+
+
+def test_tzif_reader_on_real_and_damaged_zone_files(hostcheck, tmp_path):
+    import tzdata
+    zi = os.path.join(os.path.dirname(tzdata.__file__), "zoneinfo")
+    rng = random.Random(7)
+    for zone in ("Europe/Berlin", "America/New_York", "Asia/Kolkata", "Australia/Lord_Howe", "Africa/Casablanca", "UTC"):
+        src = os.path.join(zi, zone)
+        assert run(hostcheck, "tz", src)["ok"] == 1
+        data = open(src, "rb").read()
+        for k in range(60):
+            m = bytearray(data)
+            if k % 3 == 0:
+                m = m[:rng.randrange(0, len(m))]
+            else:
+                for _ in range(rng.choice((1, 2, 6))):
+                    m[rng.randrange(len(m))] = rng.randrange(256)
+            p = tmp_path / "z"
+            p.write_bytes(bytes(m))
+            run(hostcheck, "tz", p)  # ok or not: it returns
+
+
+def test_row_selection_stepping_invariants(hostcheck):
+    out = run(hostcheck, "select", 11, 4000)
+    assert out["selections"] == 4000 and out["batches"] > 0
+
+
+def test_the_oracle_under_its_own_sanitizer_build():
+    """oracle/Makefile's liborc_oracle_asan.so, run by something at last: the known-answer vectors and the codec tests once more,
+    the library swapped for its ASan / UBSan build (ORC_ORACLE_SO; libasan preloaded into the Python process)."""
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("no libasan.so beside gcc")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liborc_oracle_asan.so"])
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:exitcode=99", UBSAN_OPTIONS="halt_on_error=1:exitcode=98",
+               ORC_ORACLE_SO=os.path.join(ROOT, "oracle", "liborc_oracle_asan.so"))
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_oracle_kat.py"),
+                        os.path.join(ROOT, "tests", "test_oracle_codecs.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, p.stdout.decode()[-4000:]
