@@ -882,6 +882,9 @@ def main():
         "end_to_end_ms_per_stripe": round(e2e_dt / len(stripes) * 1e3, 3) if e2e_dt > 0 else None,
         "setup": {"generate_s": round(plan["gen_s"], 2), "generate_procs": plan["gen_procs"], "check_s": round(t_check, 2),
                   "checked": "skipped" if args.skip_check else ("first stripe buffer by buffer + every stripe by whole-buffer sums" if args.workload == "lineitem" else "every stripe buffer by buffer")},
+        # device memory in use at the end of the run (staged streams, workspace, results, pinned mirrors do not count): what decides
+        # which table sizes fit one GPU's 288 GB
+        "hbm_bytes_in_use": (lambda fr_to: int(fr_to[1] - fr_to[0]))(torch.cuda.mem_get_info()),
         "roofline": dict(roof, whole_step_frac=round((stream_bytes + arrow_bytes) / (my_dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)),
         "lanes": lanes_of(lane_acc),
     }

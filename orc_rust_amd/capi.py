@@ -240,7 +240,7 @@ class Context:
             pass
 
     def error(self):
-        return self.L.orcgpu_last_error(self.h).decode()
+        return self.L.orcgpu_last_error(self.h).decode("utf-8", "replace")  # (a message may quote bytes of a damaged file)
 
     def _check(self, rc):
         if rc:

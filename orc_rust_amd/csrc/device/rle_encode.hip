@@ -818,8 +818,10 @@ extern "C" __global__ void __launch_bounds__(256) enc_bytes_to_bits_kernel(const
 }
 // the lengths of strings from their offsets (writer/column.rs:334-343) in the offsets' own width N (the length encoder is
 // RleV2Encoder<T::Offset, UnsignedEncoding>), and as u32, zero for null rows: their scan places the valid rows' bytes
+// `bad` (one word, zeroed by the host): set when a pair of offsets is not ascending or a value is 4 GiB or longer -- the Arrow
+// offsets are the caller's; a negative length cast to u32 would send the copy kernel far outside the values buffer
 extern "C" __global__ void __launch_bounds__(256) enc_lengths_kernel(const void* offsets, int offset_bytes, const uint8_t* validity, uint64_t n_rows, void* lengths,
-                                                                     uint32_t* vlen) {
+                                                                     uint32_t* vlen, uint32_t* bad) {
   const uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (row >= n_rows) return;
   int64_t len;
@@ -831,6 +833,10 @@ extern "C" __global__ void __launch_bounds__(256) enc_lengths_kernel(const void*
     ((int64_t*)lengths)[row] = len;
   }
   const bool valid = !validity || ((validity[row >> 3] >> (row & 7)) & 1);
+  if (len < 0 || len > 0xffffffffll) {
+    *bad = 1;
+    len = 0;
+  }
   vlen[row] = valid ? (uint32_t)len : 0u;
 }
 // the valid rows' bytes one behind the other: a wavefront per row (row_dst: exclusive scan of vlen)

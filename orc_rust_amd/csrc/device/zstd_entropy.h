@@ -438,11 +438,7 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
         const uint32_t waddr = bits_lds + (uint32_t)(B - origin);
         const uint32_t addr = tbase + (has_tab ? state << 3 : 0u);
         const uint64_t e = *reinterpret_cast<const __attribute__((address_space(3))) uint64_t*>((uintptr_t)addr);
-#if defined(ZEXP) && ZEXP == 2
-        uint64_t word = (uint64_t)waddr * 0x9e3779b97f4a7c15ull;
-#else
         uint64_t word = *reinterpret_cast<const __attribute__((address_space(3))) uint64_t*>((uintptr_t)waddr);
-#endif
         uint32_t e0 = (uint32_t)e, e1 = (uint32_t)(e >> 32);
         asm volatile("" : "+v"(e0), "+v"(e1), "+v"(word));  // both reads are in flight together: ONE LDS latency per sequence
         const uint32_t cnt = (e0 >> sh) & 0xffu;
@@ -470,9 +466,7 @@ __device__ __forceinline__ int zfse_sequences(ZEntLds& L, const uint8_t* q_, uin
         state = is_x ? mirrored : nv;
         T -= total;
       }
-#if !defined(ZEXP) || ZEXP != 1
       if (k) flush(i, k);
-#endif
       i += k;
       if (wide) break;
     }

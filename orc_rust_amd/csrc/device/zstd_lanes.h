@@ -37,12 +37,8 @@
 #define ZQ_ROOM (ZQ_RING - 66)              // the next 64 bytes fit below `fill` once the cursor is within this many bytes of it
 #define ZQ_XROW 80                          // bytes of a row of the values on their way out (16 values + padding: see put_vals)
 
-// EXP: 0 = the kernel; other values are timing experiments of a development build (-DZQ_DEV: the same steps with one ingredient
-// taken out, launched without stores behind the real kernel -- ORCGPU_ZSTD_K2_EXTRA)
-template <int EXP>
 __device__ __forceinline__ void zstd_seq_quads_body(const ZBlock* __restrict__ blocks, uint32_t n_chains, const uint16_t* ztab_, const ZSeqHdr* zhdr_, uint32_t* status_out_,
-                                                    uint32_t flags, uint16_t* tabs, uint8_t* rings, uint8_t* xpose) {
-  // flags (timing experiments, ORCGPU_ZSTD_K2_EXTRA): 1 = no stores, 2 = no refill loads (garbage results, the same steps)
+                                                    uint16_t* tabs, uint8_t* rings, uint8_t* xpose) {
   const uint32_t lane = threadIdx.x;
   const uint32_t first = blockIdx.x * 16u;
   if (first >= n_chains) return;
@@ -106,7 +102,7 @@ __device__ __forceinline__ void zstd_seq_quads_body(const ZBlock* __restrict__ b
   uint8_t* const rg = rings + cw * ZQ_RING_BYTES;
   auto load16 = [&](int b0) -> uint4 {  // stream bytes [b0, b0 + 16): zeros outside the stream (at most 15 bytes behind it are read: slack of the arena)
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (b0 >= 0 && (uint32_t)b0 < qn && !(flags & 2u)) {
+    if (b0 >= 0 && (uint32_t)b0 < qn) {
       const uint64_t a = ld_u64(q + b0), b = ld_u64(q + b0 + 8);
       v = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
     }
@@ -130,17 +126,6 @@ __device__ __forceinline__ void zstd_seq_quads_body(const ZBlock* __restrict__ b
     const int B = (top - 57) >> 3;
     t8 = top - 8 * B;
     uint64_t w;
-    if (EXP == 1) return (uint64_t)(uint32_t)top * 0x9e3779b97f4a7c15ull;  // no window read
-    if (EXP == 5) return *reinterpret_cast<const uint64_t*>(rg + ((uint32_t)B & (ZQ_RING - 8u)));  // an aligned one
-    if (EXP == 6) {  // ds_read_b64 at a 4-byte aligned address
-      const uint32_t a = (uint32_t)(uintptr_t)(rg + ((uint32_t)B & (ZQ_RING - 4u)));
-      asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(a) : "memory");
-      return w;
-    }
-    if (EXP == 7) {  // two dwords (ds_read2_b32)
-      __builtin_memcpy(&w, __builtin_assume_aligned(rg + ((uint32_t)B & (ZQ_RING - 4u)), 4), 8);
-      return w;
-    }
     __builtin_memcpy(&w, rg + ((uint32_t)B & (ZQ_RING - 1u)), 8);
     return w;
   };
@@ -171,9 +156,6 @@ __device__ __forceinline__ void zstd_seq_quads_body(const ZBlock* __restrict__ b
   // cell is what the chain waits for, the window is only needed ~35 instructions later, when the fields are cut out.  (Read a step
   // ahead -- as soon as the widths of the step before are added up -- the window sat in FRONT of the next cell read in the in-order
   // LDS queue: 6.2 instead of 4.2 ms for the kernel without its stores.)
-  int t8n = 0;
-  uint64_t xn = 0;
-  if (EXP == 8) xn = window_at(P, t8n);
 
   // The sixteen values a lane has collected leave at the NEXT visit to memory, behind its fetch: loads and stores share one
   // in-order counter, so the wait for a fetched block is also a wait for every store issued before it -- stores issued at the end
@@ -188,7 +170,6 @@ __device__ __forceinline__ void zstd_seq_quads_body(const ZBlock* __restrict__ b
   uint8_t* const xrow = xpose + (cw * 3u + (r < 3 ? r : 0u)) * ZQ_XROW;  // this lane's row (values of steps 0..15)
   const uint8_t* const xq = xpose + cw * 3u * ZQ_XROW + r * 8u;           // the quad's rows, at this lane's two steps of each half
   auto put_vals = [&](uint32_t at) {  // the values of steps [at, at + ZQ_STEPS)
-    if (flags & 1u) return;
     if (r < 3) {
 #pragma unroll
       for (int k = 0; k < ZQ_STEPS / 4; k++) *reinterpret_cast<uint4*>(xrow + 16 * k) = make_uint4(val[4 * k], val[4 * k + 1], val[4 * k + 2], val[4 * k + 3]);
@@ -205,7 +186,7 @@ __device__ __forceinline__ void zstd_seq_quads_body(const ZBlock* __restrict__ b
       const uint2 a = zseq_pack(o2.x, ma, la), b = zseq_pack(o2.y, mb, lb);
       const uint32_t i = at + 8u * (uint32_t)h + 2u * r;
       // (an array is padded to an even number of records: a pair that starts inside it ends inside its padding)
-      if (i < nseq && (EXP != 13 || n_chains == 0xffffffffu)) *reinterpret_cast<uint4*>(so8 + i) = make_uint4(a.x, a.y, b.x, b.y);  // (13: everything but the store)
+      if (i < nseq) *reinterpret_cast<uint4*>(so8 + i) = make_uint4(a.x, a.y, b.x, b.y);
     }
     lds_order();
   };
@@ -234,10 +215,9 @@ __device__ __forceinline__ void zstd_seq_quads_body(const ZBlock* __restrict__ b
 #pragma unroll
     for (int k = 0; k < ZQ_STEPS; k++) {
       const uint32_t i = i0 + (uint32_t)k;
-      const uint32_t cell = EXP == 4 ? ((s * 2654435761u) >> 16 | 64u) & 0xffffu : tabs[tb + s];  // (4: no cell read)
-      uint64_t x = xn;
-      int t8 = t8n;
-      if (EXP != 8) x = window_at(P, t8);  // (8: the window read a step ahead, in front of the cell read)
+      const uint32_t cell = tabs[tb + s];
+      int t8 = 0;
+      const uint64_t x = window_at(P, t8);
       const uint32_t sym = cell & 63u, ns = cell >> 6;
       const uint32_t nb = (uint32_t)__builtin_clz(ns) - c0;
       const uint32_t next = (ns << (nb & 31u)) - size;
@@ -247,7 +227,7 @@ __device__ __forceinline__ void zstd_seq_quads_body(const ZBlock* __restrict__ b
       const int tA = (int)sym - (int)cA;
       const uint32_t half = (uint32_t)(tA >> 1) > 1u ? (uint32_t)(tA >> 1) : 1u;
       const uint32_t lenb = tA < 0 ? 0u : (sym < cC ? half : sym - cD);
-      const uint32_t xb = EXP == 3 ? (sym & 7u) : (r == 0 ? sym : lenb) & 31u;
+      const uint32_t xb = (r == 0 ? sym : lenb) & 31u;
       // the widths of the quad's six fields: they follow each other downwards -- offset, match length, literal length extra
       // bits, then LL, ML, OF state bits
       const uint32_t b0 = ZQ_BCAST(xb, 0), b1 = ZQ_BCAST(xb, 1), b2 = ZQ_BCAST(xb, 2);
@@ -260,7 +240,6 @@ __device__ __forceinline__ void zstd_seq_quads_body(const ZBlock* __restrict__ b
       if (i + 1 == nseq) Pfin = P - (int)e3;
       const int Pk = P;
       P -= (int)total;
-      if (EXP == 8) xn = window_at(P, t8n);
       uint32_t xv = (uint32_t)(x >> (((uint32_t)t8 - xend) & 63u)) & mask(xb);
       uint32_t sv = (uint32_t)(x >> (((uint32_t)t8 - send) & 63u)) & mask(nb);
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(total > 57u) != 0ull, 0)) {
@@ -280,24 +259,13 @@ __device__ __forceinline__ void zstd_seq_quads_body(const ZBlock* __restrict__ b
   }
   if (maxn) put_vals((maxn - 1u) & ~(uint32_t)(ZQ_STEPS - 1));
   if (!st && Pfin != 0) st = Pfin < 0 ? 23 : 24;  // the stream ran dry / every bit must be used
-  if (has && r == 0 && !flags) status_out[c] = (uint32_t)st;
+  if (has && r == 0) status_out[c] = (uint32_t)st;
 }
 
 extern "C" __global__ void __launch_bounds__(64) zstd_seq_quads_kernel(const ZBlock* __restrict__ blocks, uint32_t n_chains, const uint16_t* ztab_,
-                                                                      const ZSeqHdr* zhdr_, uint32_t* status_out_, uint32_t flags) {
+                                                                      const ZSeqHdr* zhdr_, uint32_t* status_out_) {
   __shared__ __attribute__((aligned(16))) uint16_t tabs[16 * ZL_CELLS];
   __shared__ __attribute__((aligned(16))) uint8_t rings[16 * ZQ_RING_BYTES];
   __shared__ __attribute__((aligned(16))) uint8_t xpose[48 * ZQ_XROW + 512];  // (+ the base values of the length codes)
-  zstd_seq_quads_body<0>(blocks, n_chains, ztab_, zhdr_, status_out_, flags, tabs, rings, xpose);
+  zstd_seq_quads_body(blocks, n_chains, ztab_, zhdr_, status_out_, tabs, rings, xpose);
 }
-#ifdef ZQ_DEV
-template <int EXP>
-__global__ void __launch_bounds__(64) zstd_seq_quads_exp(const ZBlock* __restrict__ blocks, uint32_t n_chains, const uint16_t* ztab_, const ZSeqHdr* zhdr_, uint32_t* status_out_,
-                                                         uint32_t flags) {
-  __shared__ __attribute__((aligned(16))) uint16_t tabs[16 * ZL_CELLS];
-  __shared__ __attribute__((aligned(16))) uint8_t rings[16 * ZQ_RING_BYTES];
-  __shared__ __attribute__((aligned(16))) uint8_t xpose[48 * ZQ_XROW + 512];  // (+ the base values of the length codes)
-  if (EXP == 12 && n_chains == 0xffffffffu) xpose[threadIdx.x] = 1;  // (12: no stores, but the LDS of the kernel that has them)
-  zstd_seq_quads_body<EXP>(blocks, n_chains, ztab_, zhdr_, status_out_, EXP == 9 ? 2u : (EXP == 10 || EXP == 13 ? 0x10u : flags | 1u), tabs, rings, xpose);  // (9: stores, no fetches; 10: both)
-}
-#endif

@@ -257,6 +257,42 @@ def test_lists_and_maps_are_pruned_like_flat_columns(tmp_path):
     assert g_read < g_total, (g_read, g_total)
 
 
+def test_unions_are_pruned_like_structs(tmp_path):
+    """Stripes with Union columns (round 6; union.rs:69-136): the tag stream is entered at the row group's position like any byte-RLE
+    stream, every arm's child at the positions the child's own index entries hold for the same row group (the writer records how
+    far each column's streams have got at every boundary: for an arm's child that is the rows whose tag named it so far); how many
+    values of an arm a piece holds follows from the piece's tags."""
+    n = 40_000
+    rng = np.random.default_rng(31)
+    ids = rng.integers(0, 3, n).astype(np.int8)
+    arms = [pa.array(rng.integers(-2**40, 2**40, n), mask=rng.random(n) < 0.1),
+            pa.array(["u%d" % (i % 211) for i in range(n)], mask=rng.random(n) < 0.2),
+            pa.array(rng.random(n) < 0.5)]
+    un = pa.UnionArray.from_sparse(pa.array(ids), arms, ["l", "s", "b"])
+    table = pa.table({"id": pa.array(np.arange(n, dtype=np.int64)), "un": un, "tail": pa.array(["t%d" % (i % 7) for i in range(n)])})
+    sel = [S(17_500), K(600), S(10_000), K(1), S(999), K(1200), S(n - 17_500 - 600 - 10_000 - 1 - 999 - 1200)]
+    for comp in ("uncompressed", "zstd", "snappy"):
+        path = write(tmp_path, table, "u_%s.orc" % comp, compression=comp, compression_block_size=65536, row_index_stride=1000, stripe_size=64 << 20)
+        assert len(stripe_rows(path)) == 1
+        pruned, (g_read, g_total) = read(path, table.schema.names, sel, True, 700)
+        whole, _ = read(path, table.schema.names, sel, False, 700)
+        assert g_read < g_total == 40, (g_read, g_total)
+        assert len(pruned) == len(whole)
+        for k, (a, b) in enumerate(zip(pruned, whole)):
+            assert a.num_rows == b.num_rows and a.equals(b), ("batch", k)
+        # ... and against the table the writer was given, row by row (an arm's slots under another arm's tag are nulls here, whatever
+        # the writer's arrays held there: compared as Python values)
+        want = expected_batches(table, path, sel, 700)
+        assert len(want) == len(pruned)
+        for a, w in zip(pruned, want):
+            assert a.column("id").to_pylist() == w.column("id").to_pylist()
+            assert a.column("un").to_pylist() == w.column("un").to_pylist()
+            assert a.column("tail").to_pylist() == w.column("tail").to_pylist()
+        # a few rows of the last row group; the Union alone
+        pruned, (g_read, g_total) = read(path, ["un"], [S(n - 10), K(10)], True, 1000)
+        assert g_read == 1 and pruned[0].column("un").to_pylist() == table.column("un").slice(n - 10, 10).to_pylist()
+
+
 def test_reference_fixtures_with_and_without_index():
     """TestOrcFile.testSeek.orc / testWithoutIndex.orc (the reference's fixtures): selections over their flat columns."""
     import arrow_util as A
