@@ -123,7 +123,7 @@ def build_workload(args, rank, world):
         stripe_rows = [min(W.LINEITEM_STRIPE_ROWS, rows - lo) for lo in range(0, rows, W.LINEITEM_STRIPE_ROWS)]
         units, loads = shard.unit_shard(stripe_rows, W.LINEITEM_ARROW_BYTES_PER_ROW, world)
         mine = units[rank]
-        if args.columns:
+        if getattr(args, "columns", ""):
             keep = {int(c) - 1 for c in args.columns.split(",")}
             mine = [u for u in mine if u[1] in keep]
         desc = "all 16 columns of every stripe" if world == 1 else "(stripe, column) units x%d, LPT by Arrow bytes (not whole columns: l_comment alone is 18 %% of the bytes)" % world
