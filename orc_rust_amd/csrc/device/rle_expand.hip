@@ -203,6 +203,9 @@ __device__ __forceinline__ void expand_group(RleJob* j, const RleBlocks& blk, co
         L.soi[lane * K + k] = (uint32_t)o;
         if (CODEC == CODEC_RLE2) {
           // SHORT_REPEAT / DIRECT from the header's two bytes (rle2_hop2); whatever else there is takes the full parse
+          // (Round 6, all measured on lineitem's dictionary keys -- runs of 3 - 4 values -- and all without effect: the group's bytes
+          // staged in LDS, a 32-byte register window over the headers, groups of 16 or 64 blocks.  The kernel is bound by what it
+          // ISSUES: a hop of the chain costs its ~30 instructions for the whole wavefront, however few lanes own a block.)
           const uint32_t hw = (uint32_t)data[p] | ((uint32_t)data[p + 1] << 8);  // (the second byte may be the first of the stream's slack: ORC_PAD)
           uint32_t fsz, fn;
           if (rle2_hop2(hw & 0xff, hw >> 8, nbits, len - p, fsz, fn)) {
