@@ -737,7 +737,7 @@ __device__ __forceinline__ void block_exit_table(const uint8_t* data, uint64_t l
 template <int CODEC>
 __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint64_t len, uint32_t lb0, uint32_t b0g, uint32_t (*tabs)[2][RLE_BLK],
                                            volatile uint32_t* exits, volatile uint32_t* ready, uint32_t tid, unsigned long long live_m,
-                                           unsigned long long weak_m PROF_PARM) {
+                                           unsigned long long weak_m, uint32_t carry PROF_PARM) {
   const uint8_t* data = as_global(j->data);
   const bool is_signed = j->is_signed;
   const int nbits = j->nbits;
@@ -750,7 +750,12 @@ __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint
   // with the true chain after a few run lengths), then the span's own.  A weak block enters where its predecessor's last
   // run ended, a strong one at its verified header.
   const bool first_weak = weak_m & 1;
-  const uint32_t k0 = (nwarm > 0 && first_weak) ? 0u : nwarm;
+  // `carry` (not ~0): where the last run of the block in front of the span ends, as the span before -- walked by this workgroup a
+  // moment ago -- found it: the true chain's entry into this span's first block, no warm-up needed.  (A workgroup takes up to eight
+  // consecutive spans of a stream: seven of its eight warm-ups -- a third of the tables it built at table scale -- were for
+  // entries it already knew.)
+  const bool carried = carry != 0xffffffffu;
+  const uint32_t k0 = (nwarm > 0 && first_weak && !carried) ? 0u : nwarm;
   for (uint32_t k = k0 + wv; k < nwarm + 64; k += RLE_SHORT_WAVES) {
     const bool in_span = k >= nwarm;
     const uint32_t sl = k - nwarm;
@@ -766,6 +771,8 @@ __device__ __forceinline__ void short_span(RleJob* j, const RleBlocks& blk, uint
       if (limit) block_exit_table<CODEC>(data, len, lbv, is_signed, nbits, tabs[wv], lane, cur);
       if (!bweak) {
         e = e_given;
+      } else if (k == k0 && carried && nwarm > 0) {
+        e = carry;
       } else if (k != k0) {  // (k0: the first warm-up block, or the stream's first block: entry 0)
         uint32_t spins = 0;
         while (!ready[k - 1] && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);  // (the bound: whatever happens, the kernel ends -- and the verify rounds see the rest)
@@ -827,14 +834,20 @@ extern "C" __global__ void __launch_bounds__(64 * RLE_SHORT_WAVES, RLE_SHORT_MIN
     }
   }
   __syncthreads();
+  uint32_t carry = 0xffffffffu;  // the exit of the last block of the span before, when this workgroup has just walked it
   for (int s = 0; s < 8; s++) {
     const unsigned long long live_m = masks[s][0], weak_m = masks[s][1];
     // isolated weak blocks inside long-run streams are left to the relaxation rounds
-    if (__builtin_popcountll(weak_m) < RLE_SHORT_MIN_WEAK) continue;
+    if (__builtin_popcountll(weak_m) < RLE_SHORT_MIN_WEAK) {
+      carry = 0xffffffffu;
+      continue;
+    }
     uint32_t bw = bw8 + s * 64, lb0 = bw - j->block0;
-    if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, tabs, exits, ready, tid, live_m, weak_m PROF_ARG);
-    else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, tabs, exits, ready, tid, live_m, weak_m PROF_ARG);
-    else short_span<CODEC_BYTE>(j, blk, len, lb0, bw, tabs, exits, ready, tid, live_m, weak_m PROF_ARG);
+    if (j->codec == CODEC_RLE2) short_span<CODEC_RLE2>(j, blk, len, lb0, bw, tabs, exits, ready, tid, live_m, weak_m, carry PROF_ARG);
+    else if (j->codec == CODEC_RLE1) short_span<CODEC_RLE1>(j, blk, len, lb0, bw, tabs, exits, ready, tid, live_m, weak_m, carry PROF_ARG);
+    else short_span<CODEC_BYTE>(j, blk, len, lb0, bw, tabs, exits, ready, tid, live_m, weak_m, carry PROF_ARG);
+    // (behind short_span's closing barrier: the exits are final.  The span's last block must lie inside the stream)
+    carry = (live_m >> 63) & 1 ? exits[(lb0 >= RLE_WARM ? RLE_WARM : lb0) + 63] : 0xffffffffu;
 #ifdef ORC_PROF
     if (tid == 0) atomicAdd(&g_prof[42], 1ull);
 #endif
