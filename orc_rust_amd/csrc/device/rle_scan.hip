@@ -1107,7 +1107,9 @@ extern "C" __global__ void __launch_bounds__(64) rle_repair_kernel(RleJob* jobs,
 // others.  The stream's blocks are then exact by construction: rle_repair_kernel has nothing to do (first_bad = none).
 #define RLE_EXACT_E 4608u     // bytes from a span's start within which a chain may enter it (RLE v2: 4 + 512 * 8 + 31 * 8 patch bytes)
 #define RLE_EXACT_SPAN 256u   // blocks per span (RLE_TILE / 4)
+#ifndef RLE_EXACT_WG
 #define RLE_EXACT_WG 512
+#endif
 __device__ __forceinline__ bool exact_span(const RleJob* jobs, int njobs, const uint64_t* scalars, uint32_t g, uint32_t total_blocks, RleJob*& j,
                                            uint32_t& lb0, uint64_t& len) {
   const uint32_t bw = g * RLE_EXACT_SPAN;

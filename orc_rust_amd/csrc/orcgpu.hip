@@ -258,6 +258,7 @@ struct orcgpu_ctx {
   bool kev_used[2] = {false, false};
   hipStream_t aux_stream = nullptr;   // the Zstandard execution kernel runs here, beside the entropy kernel on `stream`
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
+  bool exact_on = false;  // the last decode call of this lane met a stream for the exact parallel walk (rle_exact_*): the next one sends it
   hipEvent_t lit_ev[2] = {nullptr, nullptr};  // around zstd_literals_kernel on the stream it runs on (orcgpu_last_lane_stats)
   bool lit_ev_used = false;
   float last_total_ms = 0, last_expand_ms = 0;
