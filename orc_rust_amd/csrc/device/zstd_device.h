@@ -259,17 +259,6 @@ __device__ __forceinline__ int huf_build_dev(uint16_t* tab, int* maxbits_out, ui
 // handing every lane its predecessor's crossing point once or twice nothing changes any more (the
 // loop runs until then: exact whatever the data, at worst as slow as one lane per stream).  Symbol
 // counts are then prefix-summed per stream and a last pass writes the symbols.
-// downward bit cursor for the Huffman streams: `pos` = code boundary (bits of the stream below it are
-// unread), `w` holds the bits just below pos left-aligned (bit pos-1 at bit 63), `avail` of them valid;
-// bits below the start of the stream read as zero.
-struct HBits {
-  const uint8_t* p;
-  uint64_t lo, hi1;  // stream bits [wb64 - 64, wb64) and [wb64, wb64 + 64) (the latter kept shifted left by one)
-  uint64_t nx[4];    // the 32 bytes below lo, highest word first: on their way while lo and hi are consumed
-  uint32_t nxi;      // words of nx taken so far
-  int wb64;          // multiple of 8; 0 <= pos - wb64 <= 63 always
-  int pos;
-};
 // 64 stream bits from bit `wb` (a multiple of 8; may lie before the stream: those bits read as zero) of the stream at q
 __device__ __forceinline__ uint64_t zl_word(const uint8_t* q, int wb) {
   const int bo = wb >> 3;
@@ -277,83 +266,58 @@ __device__ __forceinline__ uint64_t zl_word(const uint8_t* q, int wb) {
   const int neg = bo < 0 ? -bo : 0;  // bytes of the word that lie before the stream
   return neg >= 8 ? 0ull : v << (8 * neg);
 }
-// the four words below bit `wb`: nx[k] = stream bits [wb - 64 (k + 1), wb - 64 k).  ONE 32-byte piece of the stream per 256 bits of
-// codes: with a word at a time (8 bytes per load, 64 lanes 750 bytes apart, 26 wavefronts a CU) every load was a cache line from
-// memory -- the lines do not survive in L2 between a lane's loads: 13.7 GB fetched for 1.1 GB of Huffman streams (PMC, SF 12.5)
-__device__ __forceinline__ void hb_fetch4(HBits& h, int wb) {
-  const int bo = (wb - 256) >> 3;
-  if (bo >= 0) {
-    uint64_t w[4];
-    __builtin_memcpy(w, h.p + bo, 32);
-    h.nx[3] = w[0];
-    h.nx[2] = w[1];
-    h.nx[1] = w[2];
-    h.nx[0] = w[3];
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; k++) h.nx[k] = zl_word(h.p, wb - 64 * (k + 1));
-  }
-  h.nxi = 0;
-}
-// A seek costs four loads; stepping down the stream afterwards never waits for memory: the words below the window are requested
-// when the last of them is taken and needed only when the window moves again (eight bytes of codes later).  The loop used to
-// reload its window from the cursor's byte position -- a dependent load every five or six symbols in SOME lane of the wavefront,
-// i.e. in every iteration of all of them.
-__device__ __forceinline__ void hb_seek(HBits& h, int pos) {
-  h.pos = pos;
-  h.wb64 = (pos & ~7) - 56;
-  h.hi1 = zl_word(h.p, h.wb64) << 1;
-  h.lo = zl_word(h.p, h.wb64 - 64);
-  hb_fetch4(h, h.wb64 - 64);
-}
-__device__ __forceinline__ uint32_t hb_peek32(const HBits& h) {  // the 32 bits below pos, bit 31 = the next unread bit
-  const uint32_t s = (uint32_t)(h.pos - h.wb64);
-  return (uint32_t)(((h.lo >> s) | (h.hi1 << (63u - s))) >> 32);
-}
-__device__ __forceinline__ void hb_skip(HBits& h, int nb) {
-  h.pos -= nb;
-  if (h.pos < h.wb64) {
-    h.hi1 = h.lo << 1;
-    h.lo = h.nxi == 0 ? h.nx[0] : (h.nxi == 1 ? h.nx[1] : (h.nxi == 2 ? h.nx[2] : h.nx[3]));
-    h.wb64 -= 64;
-    if (++h.nxi == 4) hb_fetch4(h, h.wb64 - 64);
-  }
-}
-
-// The same cursor with its bytes in LDS (zstd_literals_kernel).  With the window refilled from memory where a lane needs it, SOME
-// lane of the wavefront issues a load in nearly every trip of the symbol loop, and the wait in front of the next use of a
-// refilled word -- one counter for the whole wavefront -- then waits for that load: a memory round trip per symbol, ~1-2 us
-// (1 650 symbol steps per lane took 1.7 ms).  Here every lane copies ZL_CHUNK bytes of its segment to LDS at once -- all lanes in the
-// same trip of an outer loop, ZL_CHUNK / 16 loads in flight per lane -- and the symbol loop touches LDS only; a lane whose chunk is
-// used up leaves the inner loop and waits for the others, who are at most some symbols behind (same code lengths on average).
 #ifndef ZL_CHUNK
-#define ZL_CHUNK 64
+#define ZL_CHUNK 64  // bytes of its segment a lane holds in LDS
 #endif
-struct HBitsL {
+
+// ---- the symbol loops of the literals, SIXTEEN SYMBOLS A TRIP (zstd_literals_kernel, zstd_entropy_kernel) -------------------------------
+// Every lane holds ZL_CHUNK bytes of its segment in LDS (round 5: with a window reloaded from memory where a lane needs it SOME lane
+// issues a load in nearly every trip of the symbol loop, and the wait in front of any lane's next use of a reloaded register -- one
+// counter for the whole wavefront -- waits for that load: a memory round trip per symbol); all lanes refill their chunk in the same
+// trip of an outer loop, the chunk below already on its way.  Round 6 replaced the symbol loop: one symbol per trip cost ~28 vector
+// and ~24 scalar instructions (-DORC_PROF + the ISA: the kernel alone is bound by what it issues -- two symbols per table cell made the
+// steps fewer and the kernel no faster) -- the window arithmetic on two 64-bit words, the accumulation of symbols at a run-time byte
+// position, and a handful of per-lane branches (segment end, chunk used up, window word used up, 16 bytes ready, bytes in front of
+// the first 16-byte boundary), each of them exec-mask bookkeeping.  Here a lane far from its segment's end decodes sixteen symbols
+// without any of the checks, ~11 vector instructions a symbol:
+//   * the window is ONE 64-bit register of unread bits, left-aligned: the table index is its high word shifted right, a symbol is
+//     consumed by one 64-bit shift;
+//   * behind every second symbol (2 x 11 bits at most out of the 32 or more the window holds) the next 32-bit word of the lane's
+//     chunk in LDS is put below the valid bits if fewer than 32 are left -- without a branch (the word is read either way);
+//   * symbol j of a trip goes to byte j of four registers (v_perm_b32 with a constant selector), which leave as one aligned store;
+//   * position, count and chunk bookkeeping once per trip: 176 bits at most, so a lane runs while its segment's end is that far off
+//     and while fewer than ten of its chunk's sixteen words are taken (six more at most in a trip); the chunks follow each other at
+//     40 bytes (ten words).
+// The symbols in front of the first 16-byte boundary of a lane's output, the last 176 bits of a segment and round 1 (which has to stand
+// on every code boundary) take the same cursor one symbol at a time.  (Literals kernel of the headline, wavefront time in the three
+// symbol loops: 14.5 M -> 8.2 M wave-us per lane of columns; the kernel beside the sequences kernel 8.3 / 9.7 -> 7.4 / 7.2 ms.)
+#define HW_STRIDE 40
+__device__ __forceinline__ uint32_t lds_ld32(uint32_t a) { return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)a); }
+__device__ __forceinline__ uint32_t lds_ld16(uint32_t a) { return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t*>((uintptr_t)a); }
+__device__ __forceinline__ void lds_st32(uint32_t a, uint32_t v) { *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>((uintptr_t)a) = v; }
+struct HWin {
   const uint8_t* p;
-  uint8_t* cb;       // this wavefront's chunk buffer: 64 x ZL_CHUNK bytes, piece-interleaved (piece j of lane l at (j * 64 + l) * 16)
-  uint64_t lo, hi1;  // as HBits
-  uint64_t pf[ZL_CHUNK / 8];  // the chunk below the one in LDS, on its way from memory while that one is decoded
-  uint32_t idx;      // words of the chunk taken so far (from its top); ZL_CHUNK / 8: used up
-  int e;             // the chunk in LDS: bytes [e - ZL_CHUNK, e) of the stream; -1: none (behind a seek)
-  int wb64;
+  uint32_t a0;      // LDS address of the word this lane takes FIRST from a chunk (the j-th: a0 + 256 j; bytes [e - 4 (j + 1), e - 4 j) of the stream)
+  uint32_t a;       // ... of the word it takes next; a0 + 2560 or more: the chunk is used up
+  uint64_t w;       // unread bits, left-aligned (bit 63 = stream bit pos - 1), zero below the valid ones
+  int av;           // valid bits of w: 32 .. 63 between symbols
+  int e;            // the chunk in LDS: stream bytes [e - 64, e); -1: none (behind a seek)
   int pos;
+  uint64_t pf[8];   // the chunk below on its way from memory
 };
-__device__ __forceinline__ void hb_seek(HBitsL& h, int pos) {
+__device__ __forceinline__ void hw_seek(HWin& h, int pos) {
   h.pos = pos;
-  h.wb64 = (pos & ~7) - 56;
-  h.idx = ZL_CHUNK / 8;  // (nothing loaded: the refill in front of the loop does)
   h.e = -1;
+  h.a = h.a0 + 2560;  // (nothing there: the refill in front of the loops loads)
+  h.av = 32;
+  h.w = 0;
 }
-__device__ __forceinline__ uint64_t hbl_word(const HBitsL& h, uint32_t idx, uint32_t lane) {  // word `idx` of the chunk, counted from its top
-  const uint32_t o = ZL_CHUNK - 8 * (idx + 1);
-  return *reinterpret_cast<const uint64_t*>(h.cb + (((o >> 4) * 64 + lane) << 4) + (o & 8));
-}
-// bytes [e - ZL_CHUNK, e) of the stream into pf (bytes before the stream read as zero)
-__device__ __forceinline__ void hbl_load(HBitsL& h, int e) {
+__device__ __forceinline__ bool hw_ready(const HWin& h) { return h.a < h.a0 + 2560; }
+// bytes [e - 64, e) of the stream into pf (bytes before the stream read as zero; up to 4 behind it are read: ORC_PAD)
+__device__ __forceinline__ void hw_load(HWin& h, int e) {
 #pragma unroll
-  for (int j = 0; j < ZL_CHUNK / 16; j++) {
-    const int bo = e - ZL_CHUNK + 16 * j;
+  for (int j = 0; j < 4; j++) {
+    const int bo = e - 64 + 16 * j;
     uint64_t v[2] = {0, 0};
     if (bo >= 0) {
       __builtin_memcpy(v, h.p + bo, 16);
@@ -365,50 +329,85 @@ __device__ __forceinline__ void hbl_load(HBitsL& h, int e) {
     h.pf[2 * j + 1] = v[1];
   }
 }
-// The next chunk: the window's two words are its top (a chunk used up leaves the window 16 bytes above its bottom: the chunks
-// follow each other at a fixed distance, ZL_CHUNK - 16 bytes, so the one after is requested at once and has a whole chunk's
-// decoding to arrive in).  Behind a seek the first chunk is waited for.
-__device__ __forceinline__ void hb_refill(HBitsL& h, bool need, uint32_t lane) {
+__device__ __forceinline__ void hw_refill(HWin& h, bool need) {
   if (need) {
+    int junk = -1;
     if (h.e < 0) {
-      h.e = (h.wb64 + 64) >> 3;
-      hbl_load(h, h.e);
+      h.e = ((h.pos + 32) >> 5) << 2;  // (a bit above pos at least: the window never holds 64 valid bits)
+      junk = 8 * h.e - h.pos;          // 1 .. 32 bits of the first word lie above pos
+      hw_load(h, h.e);
     } else {
-      h.e -= ZL_CHUNK - 16;
+      h.e -= HW_STRIDE;
+      h.a -= 2560;
     }
 #pragma unroll
-    for (int j = 0; j < ZL_CHUNK / 16; j++) {
-      const uint64_t v[2] = {h.pf[2 * j], h.pf[2 * j + 1]};
-      __builtin_memcpy(h.cb + ((j * 64 + lane) << 4), v, 16);
+    for (int k = 0; k < 8; k++) {
+      lds_st32(h.a0 + 256u * (uint32_t)(15 - 2 * k), (uint32_t)h.pf[k]);
+      lds_st32(h.a0 + 256u * (uint32_t)(14 - 2 * k), (uint32_t)(h.pf[k] >> 32));
     }
-    hbl_load(h, h.e - (ZL_CHUNK - 16));
-    h.hi1 = hbl_word(h, 0, lane) << 1;
-    h.lo = hbl_word(h, 1, lane);
-    h.idx = 2;
+    hw_load(h, h.e - HW_STRIDE);
+    if (junk >= 0) {
+      const uint64_t t = ((uint64_t)lds_ld32(h.a0) << 32) | lds_ld32(h.a0 + 256);
+      h.w = junk < 32 ? t << junk : t << 32;
+      h.av = 64 - junk;
+      h.a = h.a0 + 512;
+    }
   }
 }
-__device__ __forceinline__ bool hb_ready(const HBitsL& h) { return h.idx < ZL_CHUNK / 8; }
-__device__ __forceinline__ uint32_t hb_peek32(const HBitsL& h) {
-  const uint32_t s = (uint32_t)(h.pos - h.wb64);
-  return (uint32_t)(((h.lo >> s) | (h.hi1 << (63u - s))) >> 32);
+// behind a symbol or two: the next word of the chunk below the valid bits when fewer than 32 are left (no branch)
+__device__ __forceinline__ void hw_top(HWin& h, uint32_t word) {
+  const bool need = h.av < 32;
+  const uint64_t t = ((uint64_t)word << 32) >> (h.av & 63);  // av >= 32: nothing in the high word, the low word is dropped
+  h.w |= ((t >> 32) << 32) | (need ? (uint32_t)t : 0u);
+  h.av += need ? 32 : 0;
+  h.a += need ? 256u : 0u;
 }
-__device__ __forceinline__ void hb_skip(HBitsL& h, int nb, uint32_t lane) {
-  h.pos -= nb;
-  if (h.pos < h.wb64) {
-    h.hi1 = h.lo << 1;
-    h.lo = hbl_word(h, h.idx, lane);
-    h.wb64 -= 64;
-    h.idx++;
+// one symbol with the cursor's bookkeeping; returns the table cell (symbol | bits << 8)
+__device__ __forceinline__ uint32_t hw_step1(HWin& h, uint32_t tbase, uint32_t sh) {
+  const uint32_t word = lds_ld32(h.a);
+  const uint32_t e = lds_ld16(tbase + (((uint32_t)(h.w >> 32) >> sh) << 1));
+  const uint32_t nb = e >> 8;
+  h.w <<= nb;
+  h.av -= (int)nb;
+  h.pos -= (int)nb;
+  hw_top(h, word);
+  return e;
+}
+// N symbols (16, or 4 near a segment's end): EMIT: their bytes in acc[0 .. N / 4); returns the bits they took
+template <int N, bool EMIT>
+__device__ __forceinline__ int hw_steps(HWin& h, uint32_t tbase, uint32_t sh, uint32_t* acc) {
+  const int av0 = h.av;
+  const uint32_t a_0 = h.a;
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    const uint32_t word = lds_ld32(h.a);
+    const uint32_t e0 = lds_ld16(tbase + (((uint32_t)(h.w >> 32) >> sh) << 1));
+    const uint32_t n0 = e0 >> 8;
+    h.w <<= n0;
+    const uint32_t e1 = lds_ld16(tbase + (((uint32_t)(h.w >> 32) >> sh) << 1));
+    const uint32_t n1 = e1 >> 8;
+    h.w <<= n1;
+    h.av -= (int)(n0 + n1);
+    if constexpr (EMIT) {
+      uint32_t& r = acc[j >> 2];
+      if ((j & 3) == 0) {
+        r = __builtin_amdgcn_perm(e1, e0, 0x0c0c0400u);  // byte 0 <- e0, byte 1 <- e1
+      } else {
+        r = __builtin_amdgcn_perm(e0, r, 0x0c040100u);   // byte 2 <- e0
+        r = __builtin_amdgcn_perm(e1, r, 0x04020100u);   // byte 3 <- e1
+      }
+    }
+    hw_top(h, word);
   }
+  const int used = (av0 - h.av) + (int)((h.a - a_0) >> 3);
+  h.pos -= used;
+  return used;  // (N or more with a table zstd builds: every cell holds a code of one bit at least)
 }
-// (the cursor that reads memory: always ready, nothing to refill)
-__device__ __forceinline__ void hb_refill(HBits&, bool, uint32_t) {}
-__device__ __forceinline__ bool hb_ready(const HBits&) { return true; }
-__device__ __forceinline__ void hb_skip(HBits& h, int nb, uint32_t) { hb_skip(h, nb); }
+#define HW_FAR 176  // bits a trip of sixteen symbols may take
+#define HW_FAR4 44  // ... of four
 
-template <bool LW = false>
-__device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const uint8_t* sp, uint32_t sn, uint8_t* out, uint32_t outn, uint32_t k,
-                                              uint32_t lps, bool on PROF_PARM, uint8_t* cbuf = nullptr) {
+__device__ __forceinline__ int huf_decode_w16(const uint16_t* tab, int mb, const uint8_t* sp, uint32_t sn, uint8_t* out, uint32_t outn, uint32_t k,
+                                              uint32_t lps, bool on PROF_PARM, uint8_t* cbuf) {
   int bad = 0;
   int top = 0;
   if (on) {
@@ -417,9 +416,11 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
     top = (int)r.bits;
   }
   const uint32_t wl = threadIdx.x & 63;  // lane of the wavefront (k: lane of the stream)
-  typename std::conditional<LW, HBitsL, HBits>::type h{};
+  const uint32_t tbase = (uint32_t)(uintptr_t)tab;
+  const uint32_t sh = 32u - (uint32_t)mb;
+  HWin h{};
   h.p = sp;
-  if constexpr (LW) h.cb = cbuf;
+  h.a0 = (uint32_t)(uintptr_t)cbuf + wl * 4;
   const int B = (top + (int)lps - 1) / (int)lps;
   int pk = top - (int)k * B, pn = k + 1 == lps ? 0 : top - (int)(k + 1) * B;
   if (pk < 0) pk = 0;
@@ -441,62 +442,71 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
       cnt = 0;
       endpos = start;
       if (start > pn) {
-        hb_seek(h, start);
+        hw_seek(h, start);
         bool met = false;
         if (round == 0) {
           uint32_t limit = 16, jj = 0;
-          for (bool stop = false;;) {
-          hb_refill(h, !stop && h.pos > pn, wl);
-          while (h.pos > pn && hb_ready(h)) {
-            const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
-            const int nb = (int)(e >> 8);
-            if (nb == 0) {  // not a table zstd builds: no progress possible
-              bad = 1;
-              stop = true;
-              break;
+          auto mark = [&]() {  // (selects, not an indexed store: the marks stay in registers)
+            ck0 = jj == 0 ? h.pos : ck0;
+            ck1 = jj == 1 ? h.pos : ck1;
+            ck2 = jj == 2 ? h.pos : ck2;
+            ck3 = jj == 3 ? h.pos : ck3;
+            jj++;
+            limit <<= 2;
+          };
+          for (;;) {
+            hw_refill(h, h.pos > pn);
+            while (h.pos - pn >= HW_FAR && hw_ready(h)) {
+              if (hw_steps<16, false>(h, tbase, sh, nullptr) < 16) {  // not a table zstd builds: no progress possible
+                bad = 1;
+                h.pos = pn;
+              }
+              cnt += 16;
+              if (cnt == limit) mark();
             }
-            cnt++;
-            hb_skip(h, nb, wl);
-            if (cnt == limit) {
-              if (jj == 0) ck0 = h.pos;
-              else if (jj == 1) ck1 = h.pos;
-              else if (jj == 2) ck2 = h.pos;
-              else if (jj == 3) ck3 = h.pos;
-              jj++;
-              limit <<= 2;
+            while (h.pos - pn >= HW_FAR4 && h.pos - pn < HW_FAR && hw_ready(h)) {  // (the segment's last bits: a lane that is far from them has used its chunk up)
+              if (hw_steps<4, false>(h, tbase, sh, nullptr) < 4) {
+                bad = 1;
+                h.pos = pn;
+              }
+              cnt += 4;
+              if (cnt == limit) mark();
             }
-          }
-          if (!LW || stop || h.pos <= pn) break;
+            while (h.pos > pn && h.pos - pn < HW_FAR4 && hw_ready(h)) {
+              if (hw_step1(h, tbase, sh) < 256) {
+                bad = 1;
+                h.pos = pn;
+              }
+              cnt++;
+              if (cnt == limit) mark();
+            }
+            if (h.pos <= pn) break;
           }
         } else {
           // (marks are only trusted in round 1: later rounds -- rare -- decode their segment whole)
           uint32_t jj = round == 1 ? 0u : 4u;
           for (bool stop = false;;) {
-          hb_refill(h, !stop && h.pos > pn, wl);
-          while (h.pos > pn && hb_ready(h)) {
-            if (jj < 4) {
-              int ck = jj == 0 ? ck0 : (jj == 1 ? ck1 : (jj == 2 ? ck2 : ck3));
-              while (jj < 4 && h.pos < ck) {  // passed without standing on it (a mark never reached is -1: below everything)
-                jj++;
-                ck = jj == 1 ? ck1 : (jj == 2 ? ck2 : ck3);
+            hw_refill(h, !stop && h.pos > pn);
+            while (h.pos > pn && hw_ready(h)) {
+              if (jj < 4) {
+                int ck = jj == 0 ? ck0 : (jj == 1 ? ck1 : (jj == 2 ? ck2 : ck3));
+                while (jj < 4 && h.pos < ck) {  // passed without standing on it (a mark never reached is -1: below everything)
+                  jj++;
+                  ck = jj == 1 ? ck1 : (jj == 2 ? ck2 : ck3);
+                }
+                if (jj < 4 && h.pos == ck) {
+                  met = true;
+                  stop = true;
+                  break;
+                }
               }
-              if (jj < 4 && h.pos == ck) {
-                met = true;
-                stop = true;
-                break;
+              if (hw_step1(h, tbase, sh) < 256) {
+                bad = 1;
+                h.pos = pn;
               }
+              cnt++;
             }
-            const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
-            const int nb = (int)(e >> 8);
-            if (nb == 0) {
-              bad = 1;
-              stop = true;
-              break;
-            }
-            cnt++;
-            hb_skip(h, nb, wl);
-          }
-          if (!LW || stop || h.pos <= pn) break;
+            if (stop || h.pos <= pn) break;
           }
           if (met) {
             cnt += cnt_old - (16u << (2 * jj));  // the old path had 16 * 4^jj symbols above this mark
@@ -529,38 +539,40 @@ __device__ __forceinline__ int huf_decode_par(const uint16_t* tab, int mb, const
   if (work && !bad && start > pn) {
     // symbols leave SIXTEEN at a time, from the first 16-byte boundary of the lane's part of the output on: a lane's part lies
     // between its neighbours' -- an 8-byte store at any alignment was written to memory as the 32-byte piece around it (3.9 x the
-    // literals in HBM writes by the counters), a whole aligned 16-byte store is half a piece
+    // literals in HBM writes by the counters), a whole aligned 16-byte store is half a piece; the bytes in front of the boundary
+    // and the symbols of the segment's last bits one by one
     uint32_t i = incl - cnt;
-    uint64_t acc0 = 0, acc1 = 0;
-    uint32_t nacc = 0;
-    // (bytes up to the boundary one by one)
     uint32_t head = (uint32_t)((16u - ((uint32_t)(uintptr_t)(out + i) & 15u)) & 15u);
-    hb_seek(h, start);
+    hw_seek(h, start);
     for (;;) {
-    hb_refill(h, h.pos > pn, wl);
-    while (h.pos > pn && hb_ready(h)) {
-      const uint32_t e = tab[hb_peek32(h) >> (32 - mb)];
-      const int nb = (int)(e >> 8);
-      if (head) {
-        out[i++] = (uint8_t)e;
+      hw_refill(h, h.pos > pn);
+      while (head && h.pos > pn && hw_ready(h)) {
+        const uint32_t c = hw_step1(h, tbase, sh);
+        if (c < 256) h.pos = pn;
+        else out[i++] = (uint8_t)c;
         head--;
-      } else {
-        if (nacc < 8) acc0 |= (uint64_t)(e & 0xff) << (8 * nacc);
-        else acc1 |= (uint64_t)(e & 0xff) << (8 * (nacc - 8));
-        if (++nacc == 16) {
-          const uint64_t v[2] = {acc0, acc1};
-          __builtin_memcpy(__builtin_assume_aligned(out + i, 16), v, 16);
-          i += 16;
-          nacc = 0;
-          acc0 = acc1 = 0;
-        }
       }
-      hb_skip(h, nb, wl);
+      while (!head && h.pos - pn >= HW_FAR && hw_ready(h)) {
+        uint32_t acc[4];
+        if (hw_steps<16, true>(h, tbase, sh, acc) < 16) h.pos = pn;  // (no progress: not a table zstd builds -- round 0 has said so)
+        __builtin_memcpy(__builtin_assume_aligned(out + i, 16), acc, 16);
+        i += 16;
+      }
+      while (!head && h.pos - pn >= HW_FAR4 && h.pos - pn < HW_FAR && hw_ready(h)) {
+        uint32_t acc;
+        if (hw_steps<4, true>(h, tbase, sh, &acc) < 4) h.pos = pn;
+        __builtin_memcpy(__builtin_assume_aligned(out + i, 4), &acc, 4);
+        i += 4;
+      }
+      while (!head && h.pos > pn && h.pos - pn < HW_FAR4 && hw_ready(h)) {
+        const uint32_t c = hw_step1(h, tbase, sh);
+        if (c < 256) h.pos = pn;
+        else out[i++] = (uint8_t)c;
+      }
+      if (h.pos <= pn) break;
     }
-    if (!LW || h.pos <= pn) break;
-    }
-    for (uint32_t t = 0; t < nacc; t++) out[i + t] = (uint8_t)((t < 8 ? acc0 >> (8 * t) : acc1 >> (8 * (t - 8))));
   }
   PROF_MARK(6);
   return bad;
 }
+

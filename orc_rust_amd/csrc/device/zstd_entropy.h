@@ -8,7 +8,7 @@
 //
 // Per block this kernel
 //   1. builds the Huffman table and decodes the literal streams into the block's literal buffer
-//      (16 lanes per stream, self-synchronising restarts: huf_decode_par in zstd_device.h);
+//      (16 lanes per stream, self-synchronising restarts: huf_decode_w16 in zstd_device.h);
 //   2. builds the three FSE tables as 8-byte entries {next state, state bits, extra bits, base value};
 //   3. runs the FSE state machine -- the one serial chain of the format -- with the six bit fields of a
 //      sequence spread over six lanes (offset / match-length / literal-length extra bits, then the three
@@ -73,7 +73,7 @@ struct ZEntLds {
       uint8_t weights[256];
       FseEnt wt[64];
     } h;
-    struct {  // literals phase, behind the Huffman table and its description: every lane's piece of its stream (HBitsL, zstd_device.h)
+    struct {  // literals phase, behind the Huffman table and its description: every lane's piece of its stream (HWin, zstd_device.h)
       __attribute__((aligned(16))) uint8_t lit_pad[4096 + 256 + 64 * 8];
       __attribute__((aligned(16))) uint8_t chunk[64 * ZL_CHUNK];
     };
@@ -93,7 +93,6 @@ struct ZEntLds {
   uint16_t next[256];
   uint8_t sym[512];        // symbol of every cell while a table is being built
   __attribute__((aligned(4))) uint8_t stage[128];  // a table description on its way from memory to the parser
-  static constexpr bool kLitWindow = true;
 };
 
 // FSE decoding table with the symbol's extra bits and base value folded into every cell.  which: 0 LL, 1 OF, 2 ML.
@@ -545,8 +544,7 @@ __device__ __forceinline__ int zstd_literals_job(LDS& L, const ZBlock& B, const 
     int bad = 0;
     const uint32_t regen = B.lit_regen;
     if (B.lit_streams == 1) {
-      if constexpr (LDS::kLitWindow) bad = huf_decode_par<true>(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true PROF_ARG, L.chunk);
-      else bad = huf_decode_par(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true PROF_ARG);
+      bad = huf_decode_w16(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true PROF_ARG, L.chunk);
     } else {
       if (qn < 6) st = 13;
       else {
@@ -562,8 +560,7 @@ __device__ __forceinline__ int zstd_literals_job(LDS& L, const ZBlock& B, const 
             const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
             const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
             const uint32_t on = k < 3 ? seg : regen - 3 * seg;
-            if constexpr (LDS::kLitWindow) bad = huf_decode_par<true>(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true PROF_ARG, L.chunk);
-            else bad = huf_decode_par(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true PROF_ARG);
+            bad = huf_decode_w16(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true PROF_ARG, L.chunk);
           }
         }
       }
@@ -661,9 +658,6 @@ extern "C" __global__ void __launch_bounds__(64) zstd_entropy_kernel(const ZBloc
 // The Huffman phase needs a third of the LDS of zstd_entropy_kernel (whose allocation is sized by the FSE tables of the sequences
 // phase): 28 wavefronts per CU instead of 10.  The decoder is a chain of table lookups per lane -- what it needs is wavefronts
 // to switch to.  Job j = the literals of block j; status_out[n_blocks + j] as zstd_entropy_kernel writes it.
-#ifndef ZL_LDS_WINDOW
-#define ZL_LDS_WINDOW 1
-#endif
 struct ZLitLds {
   union {
     struct {
@@ -676,12 +670,11 @@ struct ZLitLds {
       uint16_t next[256];
       __attribute__((aligned(4))) uint8_t stage[128];
     };
-    struct {  // ... behind the table, once it is built: every lane's piece of its Huffman stream (HBitsL)
+    struct {  // ... behind the table, once it is built: every lane's piece of its Huffman stream (HWin)
       uint16_t huf_[2048];
-      __attribute__((aligned(16))) uint8_t chunk[ZL_LDS_WINDOW ? 64 * ZL_CHUNK : 16];
+      __attribute__((aligned(16))) uint8_t chunk[64 * ZL_CHUNK];
     };
   };
-  static constexpr bool kLitWindow = ZL_LDS_WINDOW != 0;
 };
 extern "C" __global__ void __launch_bounds__(64) zstd_literals_kernel(const ZBlock* __restrict__ blocks, uint32_t n_blocks, uint32_t* status_out, uint32_t* progress) {
   __shared__ ZLitLds L;
