@@ -102,11 +102,14 @@ __device__ __forceinline__ int fse_build_dev(FseEnt* t, const int16_t* norm, int
 
 // FSE table description (forward bit stream); returns bytes consumed or -1.  Uniform.
 // `stg`: 128 bytes of LDS the description is read through (one load of the wavefront instead of a dependent memory access per byte).
+// `have`: bytes of the description the caller has put there already (zstd_literals_job stages a literals section's first bytes in one go).
 __device__ __forceinline__ long fse_read_ncount_dev(const uint8_t* p, uint32_t n, int16_t* norm, int* nsym_io, int* log_out, int maxlog,
-                                                    uint32_t lane, uint8_t* stg) {
-  const uint32_t staged = n < 128u ? n : 128u;
-  if (lane < 32 && 4 * lane < staged) reinterpret_cast<uint32_t*>(stg)[lane] = ld_u32(p + 4 * lane);  // (up to 3 bytes behind the description: slack of the arena)
-  wave_sync();
+                                                    uint32_t lane, uint8_t* stg, uint32_t have = 0) {
+  const uint32_t staged = have ? (n < have ? n : have) : (n < 128u ? n : 128u);
+  if (!have) {
+    if (lane < 32 && 4 * lane < staged) reinterpret_cast<uint32_t*>(stg)[lane] = ld_u32(p + 4 * lane);  // (up to 3 bytes behind the description: slack of the arena)
+    wave_sync();
+  }
   uint32_t pos = 0;
   uint64_t bb = 0;
   int bc = 0;
@@ -304,6 +307,8 @@ struct HWin {
   int e;            // the chunk in LDS: stream bytes [e - 64, e); -1: none (behind a seek)
   int pos;
   uint64_t pf[8];   // the chunk below on its way from memory
+  uint32_t last;    // the stream's last byte (its highest set bit ends the stream), requested by hw_begin
+  int e_pre;        // hw_begin has requested stream bytes [e_pre - 64, e_pre) into pf: round 0's first chunk
 };
 __device__ __forceinline__ void hw_seek(HWin& h, int pos) {
   h.pos = pos;
@@ -329,13 +334,33 @@ __device__ __forceinline__ void hw_load(HWin& h, int e) {
     h.pf[2 * j + 1] = v[1];
   }
 }
+// In front of everything else a block needs (hw_begin is called before the block's Huffman table is built): the stream's last byte and
+// the first chunk of the lane's segment are requested TOGETHER.  Where the segment starts depends on that byte (top = its highest set
+// bit; lane k starts at top - k * ceil(top / lps)), but only by 7 + k bits: the chunk is taken from the highest start there can be
+// and the window passes over what lies above the true one.  A wavefront's first chunks are 64 lines nobody has touched: ~100 us
+// before the symbol loops could start (-DORC_PROF), now under the 50 - 100 us the table takes.
+__device__ __forceinline__ void hw_begin(HWin& h, const uint8_t* sp, uint32_t sn, uint32_t k, uint32_t lps, uint8_t* cbuf) {
+  h.p = sp;
+  h.a0 = (uint32_t)(uintptr_t)cbuf + (threadIdx.x & 63) * 4;
+  h.last = sn ? sp[sn - 1] : 0u;
+  const int T = 8 * ((int)sn - 1) + 7;                          // the highest top there can be
+  const int bmin = (T - 7 + (int)lps - 1) / (int)lps;         // the shortest segments
+  const int U = T - (int)k * bmin;                             // >= the lane's start, by 7 + k bits at most
+  h.e_pre = ((U + 32) >> 5) << 2;
+  hw_load(h, h.e_pre);
+}
 __device__ __forceinline__ void hw_refill(HWin& h, bool need) {
   if (need) {
     int junk = -1;
     if (h.e < 0) {
-      h.e = ((h.pos + 32) >> 5) << 2;  // (a bit above pos at least: the window never holds 64 valid bits)
-      junk = 8 * h.e - h.pos;          // 1 .. 32 bits of the first word lie above pos
-      hw_load(h, h.e);
+      if (h.e_pre != -1) {
+        h.e = h.e_pre;  // (requested by hw_begin)
+        h.e_pre = -1;
+      } else {
+        h.e = ((h.pos + 32) >> 5) << 2;  // (a bit above pos at least: the window never holds 64 valid bits)
+        hw_load(h, h.e);
+      }
+      junk = 8 * h.e - h.pos;  // bits of the chunk above pos: 1 .. 32, or up to 102 in hw_begin's chunk
     } else {
       h.e -= HW_STRIDE;
       h.a -= 2560;
@@ -347,10 +372,12 @@ __device__ __forceinline__ void hw_refill(HWin& h, bool need) {
     }
     hw_load(h, h.e - HW_STRIDE);
     if (junk >= 0) {
-      const uint64_t t = ((uint64_t)lds_ld32(h.a0) << 32) | lds_ld32(h.a0 + 256);
-      h.w = junk < 32 ? t << junk : t << 32;
-      h.av = 64 - junk;
-      h.a = h.a0 + 512;
+      const uint32_t jw = (uint32_t)(junk - 1) >> 5, jr = (uint32_t)junk - 32u * jw;  // whole words to pass over, 1 .. 32 bits of the next one
+      const uint32_t at = h.a0 + 256u * jw;
+      const uint64_t t = ((uint64_t)lds_ld32(at) << 32) | lds_ld32(at + 256);
+      h.w = jr < 32 ? t << jr : t << 32;
+      h.av = 64 - (int)jr;
+      h.a = at + 512;
     }
   }
 }
@@ -406,21 +433,18 @@ __device__ __forceinline__ int hw_steps(HWin& h, uint32_t tbase, uint32_t sh, ui
 #define HW_FAR 176  // bits a trip of sixteen symbols may take
 #define HW_FAR4 44  // ... of four
 
-__device__ __forceinline__ int huf_decode_w16(const uint16_t* tab, int mb, const uint8_t* sp, uint32_t sn, uint8_t* out, uint32_t outn, uint32_t k,
-                                              uint32_t lps, bool on PROF_PARM, uint8_t* cbuf) {
+// `h`: begun for this lane's stream (hw_begin: sp, sn, k, lps)
+__device__ __forceinline__ int huf_decode_w16(HWin& h, const uint16_t* tab, int mb, uint32_t sn, uint8_t* out, uint32_t outn, uint32_t k,
+                                              uint32_t lps, bool on PROF_PARM) {
   int bad = 0;
   int top = 0;
   if (on) {
-    RBits r;
-    if (!rb_init(r, sp, sn)) bad = 1;
-    top = (int)r.bits;
+    if (sn == 0 || h.last == 0) bad = 1;  // (rb_init)
+    else top = (int)(sn - 1) * 8 + (31 - __builtin_clz(h.last));
   }
-  const uint32_t wl = threadIdx.x & 63;  // lane of the wavefront (k: lane of the stream)
+  PROF_MARK(11);
   const uint32_t tbase = (uint32_t)(uintptr_t)tab;
   const uint32_t sh = 32u - (uint32_t)mb;
-  HWin h{};
-  h.p = sp;
-  h.a0 = (uint32_t)(uintptr_t)cbuf + wl * 4;
   const int B = (top + (int)lps - 1) / (int)lps;
   int pk = top - (int)k * B, pn = k + 1 == lps ? 0 : top - (int)(k + 1) * B;
   if (pk < 0) pk = 0;

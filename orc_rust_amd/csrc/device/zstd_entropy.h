@@ -92,7 +92,7 @@ struct ZEntLds {
   int16_t norm[256];
   uint16_t next[256];
   uint8_t sym[512];        // symbol of every cell while a table is being built
-  __attribute__((aligned(4))) uint8_t stage[128];  // a table description on its way from memory to the parser
+  __attribute__((aligned(4))) uint8_t stage[208];  // a table description on its way from memory to the parser (ZL_STAGE + the jump table of a Treeless block)
 };
 
 // FSE decoding table with the symbol's extra bits and base value folded into every cell.  which: 0 LL, 1 OF, 2 ML.
@@ -237,31 +237,73 @@ __device__ __forceinline__ long zfse_from_block(ZEntLds& L, ZFse* t, int* log_ou
   return -1;
 }
 
-// Huffman tree description at q (qn bytes available) -> L.h.huf; returns the bytes it takes or -1
+// wave-uniform values: tell the compiler (scalar registers, scalar branches)
+__device__ __forceinline__ uint32_t zuni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int zuni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Huffman tree description at q (qn bytes available) -> L.h.huf; returns the bytes it takes or -1.  Its first min(qn, ZL_STAGE) bytes
+// are in L.stage already (zstd_literals_job: one round trip for the header byte, the description and the jump table behind it).
+#define ZL_STAGE 192u
+// bytes a description takes, from its header byte (RFC 8878 4.2.1.1)
+__device__ __forceinline__ uint32_t zhuf_desc_bytes(uint32_t hb) { return hb >= 128 ? 1u + (hb - 127u + 1u) / 2u : 1u + hb; }
 template <class LDS>
-__device__ __forceinline__ long zhuf_tree(LDS& L, const uint8_t* q, uint32_t qn, int* maxbits, uint32_t lane) {
+__device__ __forceinline__ long zhuf_tree(LDS& L, const uint8_t* q, uint32_t qn, int* maxbits, uint32_t lane PROF_PARM) {
   if (qn < 1) return -1;
   int nw;
-  const uint32_t hb = q[0];
+  const uint32_t hb = L.stage[0];
   uint32_t used;
   if (hb >= 128) {
     nw = (int)hb - 127;
     const uint32_t nbytes = (uint32_t)(nw + 1) / 2;
     if (1 + nbytes > qn) return -1;
-    for (int i = (int)lane; i < nw; i += 64) L.h.weights[i] = (i & 1) ? (q[1 + i / 2] & 15) : (q[1 + i / 2] >> 4);
+    for (int i = (int)lane; i < nw; i += 64) L.h.weights[i] = (i & 1) ? (L.stage[1 + i / 2] & 15) : (L.stage[1 + i / 2] >> 4);  // (65 bytes at most: staged)
     used = 1 + nbytes;
     wave_sync();
   } else {
     if (1 + hb > qn) return -1;
     int nsym = 256, log;
-    const long c = fse_read_ncount_dev(q + 1, hb, L.norm, &nsym, &log, 6, lane, L.stage);
+    const long c = fse_read_ncount_dev(q + 1, hb, L.norm, &nsym, &log, 6, lane, L.stage + 1, ZL_STAGE - 1);
+    PROF_MARK(8);
     if (c < 0) return -1;
     if (fse_build_dev(L.h.wt, L.norm, nsym, log, L.next, lane)) return -1;
-    RBits r;
-    // (the weights' bit stream lies in the staged copy of the description -- hb < 128 bytes, all of them staged by
-    // fse_read_ncount_dev --: its ~16 window reloads are LDS reads, not a chain of memory round trips, 100 us a block)
-    if (!rb_init(r, L.stage + c, hb - (uint32_t)c)) return -1;
-    uint32_t s1 = (uint32_t)rb_read(r, (uint32_t)log), s2 = (uint32_t)rb_read(r, (uint32_t)log);
+    PROF_MARK(9);
+    // The weights are ONE chain: two FSE states take turns on a backward bit stream, 100 - 250 steps a table.  With the cells in LDS
+    // and the stream read through a window in LDS every step was two dependent LDS reads and ~60 instructions (63 us a block, a
+    // tenth of the literals kernel, -DORC_PROF).  The table has 64 cells at most and the stream 127 bytes: lane i keeps cell i, lane j
+    // dword j of the stream, a step reads both with v_readlane (the state and the bit position are wave-uniform: scalar registers)
+    // and files the weight in the lane of its number -- no memory access in the loop.
+    const uint32_t sn = hb - (uint32_t)c;
+    const uint8_t* sb = L.stage + 1 + c;
+    if (sn == 0 || sb[sn - 1] == 0) return -1;
+    const uint32_t cellv = lane < (1u << log) ? *reinterpret_cast<const uint32_t*>(&L.h.wt[lane]) : 0u;  // sym | nb << 8 | base << 16
+    uint32_t dwv = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++)
+      if (4 * lane + t < sn) dwv |= (uint32_t)sb[4 * lane + t] << (8 * t);
+    int P = (int)zuni((sn - 1) * 8 + (uint32_t)(31 - __builtin_clz((uint32_t)sb[sn - 1])));  // unread bits (RBits::bits)
+    auto cell = [&](uint32_t st) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)cellv, (int)zuni(st)); };
+    auto rd = [&](uint32_t nb) -> uint32_t {  // rb_read: the nb bits below bit P; bits before the stream read as zero
+      if (nb == 0) return 0u;
+      const int start = P - (int)nb;
+      uint32_t v = 0;
+      if (start >= 0) {
+        const uint32_t lo = (uint32_t)start >> 5;
+        const uint64_t two = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dwv, (int)lo) |
+                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dwv, (int)(lo + 1)) << 32;  // (lane 32 at most: zero there)
+        v = (uint32_t)(two >> (start & 31)) & ((1u << nb) - 1u);
+      } else if (P > 0) {
+        const uint32_t have = (uint32_t)__builtin_amdgcn_readlane((int)dwv, 0) & ((1u << P) - 1u);  // (P < nb <= 6)
+        v = (have << (-start)) & ((1u << nb) - 1u);
+      }
+      P = start;
+      return v;
+    };
+    uint32_t s1 = rd((uint32_t)log), s2 = rd((uint32_t)log);
+    uint32_t wsv[4] = {0, 0, 0, 0};  // weight number r * 64 + lane
+    auto put = [&](int at, uint32_t w) {
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if ((at >> 6) == r) wsv[r] = (int)lane == (at & 63) ? w : wsv[r];
+    };
     nw = 0;
     int fail = 0;
     for (;;) {
@@ -269,30 +311,35 @@ __device__ __forceinline__ long zhuf_tree(LDS& L, const uint8_t* q, uint32_t qn,
         fail = 1;
         break;
       }
-      if (lane == 0) L.h.weights[nw] = L.h.wt[s1].sym;
+      const uint32_t c1 = cell(s1);
+      put(nw, c1 & 0xffu);
       nw++;
-      if (r.bits < (long)L.h.wt[s1].nb) {
-        if (lane == 0) L.h.weights[nw] = L.h.wt[s2].sym;
+      if (P < (int)((c1 >> 8) & 0xffu)) {
+        put(nw, cell(s2) & 0xffu);
         nw++;
         break;
       }
-      s1 = L.h.wt[s1].base + (uint32_t)rb_read(r, L.h.wt[s1].nb);
+      s1 = (c1 >> 16) + rd((c1 >> 8) & 0xffu);
       if (nw >= 254) {
         fail = 1;
         break;
       }
-      if (lane == 0) L.h.weights[nw] = L.h.wt[s2].sym;
+      const uint32_t c2 = cell(s2);
+      put(nw, c2 & 0xffu);
       nw++;
-      if (r.bits < (long)L.h.wt[s2].nb) {
-        if (lane == 0) L.h.weights[nw] = L.h.wt[s1].sym;
+      if (P < (int)((c2 >> 8) & 0xffu)) {
+        put(nw, cell(s1) & 0xffu);
         nw++;
         break;
       }
-      s2 = L.h.wt[s2].base + (uint32_t)rb_read(r, L.h.wt[s2].nb);
+      s2 = (c2 >> 16) + rd((c2 >> 8) & 0xffu);
     }
+#pragma unroll
+    for (int r = 0; r < 4; r++) L.h.weights[r * 64 + (int)lane] = (uint8_t)wsv[r];
     if (fail) return -1;
     used = 1 + hb;
     wave_sync();
+    PROF_MARK(10);
   }
   if (huf_build_dev(L.h.huf, maxbits, L.h.weights, nw, lane, reinterpret_cast<uint8_t*>(L.norm))) return -1;  // (norm: free once the weights are decoded)
   return (long)used;
@@ -307,9 +354,6 @@ __device__ __forceinline__ long zhuf_tree(LDS& L, const uint8_t* q, uint32_t qn,
 // Lane k and lane 7-k share a table (row_half_mirror hands the new state from the state lane to the value lane).
 #define ZDPP(x, ctrl) __builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xf, 0xf, false)
 
-// wave-uniform values: tell the compiler (scalar registers, scalar branches)
-__device__ __forceinline__ uint32_t zuni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ int zuni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // Decodes nseq sequences of one block.  Returns 0, or a nonzero diagnostic code.
 // The backward bit stream q[0 .. qn) is read from its last set bit downwards.  It is held in registers: lane j of `cur`
 // has dword (top - 63 + j) counted from `base` (q rounded down to 4 bytes), `nxt` the segment 48 dwords further down.
@@ -528,44 +572,64 @@ __device__ __forceinline__ int zstd_literals_job(LDS& L, const ZBlock& B, const 
   PROF_MARK(0);
   const uint8_t* q = src + B.content_off + B.lit_hdr;
   uint32_t qn = B.lit_comp;
-  if (B.lit_type == 2) {
-    const long used = zhuf_tree(L, q, qn, &mb, lane);
-    if (used < 0) st = 11;
+  // ONE round trip for everything in front of the streams: the tree description (the block's own, or -- Treeless -- that of the block
+  // that last described one, same frame) and this block's jump table (behind its own description; Treeless: at q) go to L.stage
+  // together; the header byte tells how long the description is, i.e. where the streams are, BEFORE the table is built:
+  // their last bytes and the lanes' first chunks are requested at once (hw_begin) and arrive while the table is built.
+  const bool own = B.lit_type == 2;
+  const uint8_t* td = own ? q : src + B.huf_off;
+  const uint32_t tdn = own ? qn : B.huf_end - B.huf_off;
+  {
+    const uint32_t nst = tdn < ZL_STAGE ? tdn : ZL_STAGE;
+    uint32_t* st32 = reinterpret_cast<uint32_t*>(L.stage);
+    if (4 * lane < nst) st32[lane] = ld_u32(td + 4 * lane);  // (up to 3 bytes behind the section: slack of the arena)
+    if (!own && lane >= ZL_STAGE / 4 && lane < ZL_STAGE / 4 + 2 && 4 * (lane - ZL_STAGE / 4) < qn) st32[lane] = ld_u32(q + 4 * (lane - ZL_STAGE / 4));
+    wave_sync();
+  }
+  PROF_MARK(7);
+  const uint32_t used = own && qn ? zhuf_desc_bytes(L.stage[0]) : 0u;  // (134 at most with its jump table: staged)
+  const uint32_t jt = own ? used : ZL_STAGE;                             // where the jump table's six bytes stand in L.stage
+  HWin h{};
+  h.e_pre = -1;
+  uint32_t sn = 0, sk = lane, lps = 64, sout = 0, son = B.lit_regen;  // this lane's stream: bytes, lane in it, lanes per stream, output
+  if (used > qn) st = 11;
+  else {
+    q += used;
+    qn -= used;
+    if (B.lit_streams == 1) {
+      sn = qn;
+      hw_begin(h, q, sn, sk, lps, L.chunk);
+    } else if (qn < 6) st = 13;
     else {
-      q += used;
-      qn -= (uint32_t)used;
+      const uint32_t s1 = L.stage[jt] | (L.stage[jt + 1] << 8), s2 = L.stage[jt + 2] | (L.stage[jt + 3] << 8), s3 = L.stage[jt + 4] | (L.stage[jt + 5] << 8);
+      const uint32_t seg = (B.lit_regen + 3) / 4;
+      if (6 + s1 + s2 + s3 > qn) st = 14;
+      else if (seg * 3 > B.lit_regen) st = 15;
+      else {
+        const uint32_t s4 = qn - 6 - s1 - s2 - s3;
+        const uint32_t k = lane >> 4;  // stream of this lane (16 lanes each)
+        const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
+        sn = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
+        sk = lane & 15;
+        lps = 16;
+        sout = k * seg;
+        son = k < 3 ? seg : B.lit_regen - 3 * seg;
+        hw_begin(h, q + 6 + so, sn, sk, lps, L.chunk);
+      }
     }
-  } else {
-    // Treeless: the table of the block that last described one (same frame)
-    if (zhuf_tree(L, src + B.huf_off, B.huf_end - B.huf_off, &mb, lane) < 0) st = 12;
+  }
+  if (!st) {
+    if (own) {
+      if (zhuf_tree(L, td, tdn, &mb, lane PROF_ARG) < 0) st = 11;
+    } else {
+      // Treeless: the table of the block that last described one (same frame)
+      if (zhuf_tree(L, td, tdn, &mb, lane PROF_ARG) < 0) st = 12;
+    }
   }
   PROF_MARK(1);
   if (!st) {
-    int bad = 0;
-    const uint32_t regen = B.lit_regen;
-    if (B.lit_streams == 1) {
-      bad = huf_decode_w16(L.h.huf, mb, q, qn, lit_out, regen, lane, 64, true PROF_ARG, L.chunk);
-    } else {
-      if (qn < 6) st = 13;
-      else {
-        const uint32_t s1 = q[0] | (q[1] << 8), s2 = q[2] | (q[3] << 8), s3 = q[4] | (q[5] << 8);
-        if (6 + s1 + s2 + s3 > qn) st = 14;
-        else {
-          const uint32_t s4 = qn - 6 - s1 - s2 - s3;
-          const uint32_t seg = (regen + 3) / 4;
-          if (seg * 3 > regen) st = 15;
-          else {
-            const uint8_t* bp = q + 6;
-            const uint32_t k = lane >> 4;  // stream of this lane (16 lanes each)
-            const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
-            const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
-            const uint32_t on = k < 3 ? seg : regen - 3 * seg;
-            bad = huf_decode_w16(L.h.huf, mb, bp + so, sl, lit_out + k * seg, on, lane & 15, 16, true PROF_ARG, L.chunk);
-          }
-        }
-      }
-    }
-    if (!st && __ballot(bad != 0)) st = 16;
+    const int bad = huf_decode_w16(h, L.h.huf, mb, sn, lit_out + sout, son, sk, lps, true PROF_ARG);
+    if (__ballot(bad != 0)) st = 16;
   }
   wave_sync();
   PROF_MARK(2);
@@ -668,7 +732,7 @@ struct ZLitLds {
       } h;
       int16_t norm[256];
       uint16_t next[256];
-      __attribute__((aligned(4))) uint8_t stage[128];
+      __attribute__((aligned(4))) uint8_t stage[208];
     };
     struct {  // ... behind the table, once it is built: every lane's piece of its Huffman stream (HWin)
       uint16_t huf_[2048];
