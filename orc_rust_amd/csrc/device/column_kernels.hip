@@ -260,14 +260,20 @@ extern "C" __global__ void __launch_bounds__(256) pres_validity_kernel(const Pre
 }
 
 // Null spacing for fixed-width values: out[i] = valid(i) ? dense[rank(i)] : 0   (encoding/mod.rs:64-91)
+// `limit`: dense values there are to read.  (Float / Double values are spaced straight out of their stream: a stream that is shorter
+// than its column's non-null rows -- or missing: a stripe footer that lost it, tests/test_gpu_containers.py -- fails the column
+// (float_check_body), and nothing behind its end may be touched on the way there.)
 template <typename T>
-__device__ __forceinline__ void space_body(const T* dense, const unsigned long long* vbits, const uint32_t* rank, T* out, uint64_t n_rows) {
+__device__ __forceinline__ void space_body(const T* dense, const unsigned long long* vbits, const uint32_t* rank, T* out, uint64_t n_rows, uint64_t limit) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_rows) return;
   unsigned long long word = vbits[i >> 6];
   uint32_t bit = i & 63;
   T v = T(0);
-  if ((word >> bit) & 1) v = dense[(uint64_t)rank[i >> 6] + __builtin_popcountll(word & ((1ull << bit) - 1))];
+  if ((word >> bit) & 1) {
+    const uint64_t at = (uint64_t)rank[i >> 6] + __builtin_popcountll(word & ((1ull << bit) - 1));
+    if (at < limit) v = dense[at];
+  }
   out[i] = v;
 }
 
@@ -279,14 +285,15 @@ struct SpaceJob {
   void* out;
   uint64_t n_rows;
   uint32_t width, pad;
+  uint64_t limit;  // dense values that may be read (a dense buffer of the decoders holds one per row: ~0)
 };
 extern "C" __global__ void __launch_bounds__(256) space_multi_kernel(const SpaceJob* jobs) {
   const SpaceJob j = jobs[blockIdx.y];
   if ((uint64_t)blockIdx.x * 256 >= j.n_rows) return;
-  if (j.width == 8) space_body((const int64_t*)j.dense, j.vbits, j.rank, (int64_t*)j.out, j.n_rows);
-  else if (j.width == 4) space_body((const int32_t*)j.dense, j.vbits, j.rank, (int32_t*)j.out, j.n_rows);
-  else if (j.width == 2) space_body((const int16_t*)j.dense, j.vbits, j.rank, (int16_t*)j.out, j.n_rows);
-  else space_body((const int8_t*)j.dense, j.vbits, j.rank, (int8_t*)j.out, j.n_rows);
+  if (j.width == 8) space_body((const int64_t*)j.dense, j.vbits, j.rank, (int64_t*)j.out, j.n_rows, j.limit);
+  else if (j.width == 4) space_body((const int32_t*)j.dense, j.vbits, j.rank, (int32_t*)j.out, j.n_rows, j.limit);
+  else if (j.width == 2) space_body((const int16_t*)j.dense, j.vbits, j.rank, (int16_t*)j.out, j.n_rows, j.limit);
+  else space_body((const int8_t*)j.dense, j.vbits, j.rank, (int8_t*)j.out, j.n_rows, j.limit);
 }
 
 // The summary of a decode call (scalars, job records, null counts: some KB) goes to the host through this kernel -- stores into

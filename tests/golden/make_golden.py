@@ -98,6 +98,11 @@ def main():
     os.makedirs(edge, exist_ok=True)
     for n in EDGE:
         shutil.copyfile(os.path.join(REF, "integration", "data", n), os.path.join(edge, os.path.basename(n)))
+    # a Decimal column whose precision reads 0 (what the container fuzz of tests/test_gpu_containers.py once produced): one bit of
+    # alltypes.zlib.orc's footer flipped
+    broken = bytearray(open(os.path.join(REF, "basic", "data", "alltypes.zlib.orc"), "rb").read())
+    broken[1339] ^= 0x20
+    open(os.path.join(edge, "decimal_precision_0.orc"), "wb").write(bytes(broken))
     print("done")
 
 
