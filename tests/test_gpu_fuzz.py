@@ -5,10 +5,20 @@ failing batch.  The corrupted half overwrites one byte of one stream; the refere
 import numpy as np
 import pytest
 
+import os
+
 import fuzz_gen as F
 import gpu_util as G
 
 pytestmark = pytest.mark.gpu
+
+# ORCGPU_FUZZ_CAMPAIGN=k (k = 1, 2, ...): the same tests over OTHER seeds -- every range below shifted by k * 10 000 -- for a
+# campaign beside the suite; 0 (the suite): the ranges as they stand, so that a failure comes back.
+SHIFT = 10_000 * int(os.environ.get("ORCGPU_FUZZ_CAMPAIGN", "0"))
+
+
+def seeds(lo, hi):
+    return range(lo + SHIFT, hi + SHIFT)
 
 # seeds that once exposed a bug, kept forever:
 #  200036 FLOAT short DATA behind nulls (error batch through the non-null index)
@@ -38,14 +48,14 @@ def run_case(seed, corrupt):
 
 
 def test_valid_stripes():
-    for seed in range(7_000_000, 7_000_300):
+    for seed in seeds(7_000_000, 7_000_300):
         run_case(seed, False)
 
 
 def test_corrupted_stripes_fail_like_the_oracle():
     for seed in REGRESSIONS:
         run_case(seed, True)
-    for seed in range(7_100_000, 7_100_600):
+    for seed in seeds(7_100_000, 7_100_600):
         run_case(seed, True)
 
 
@@ -77,23 +87,23 @@ def run_stripe_case(seed, hits):
 def test_stripes_with_several_corrupted_bytes():
     for seed, hits in MULTI:
         run_stripe_case(seed, hits)
-    for seed in range(7_200_000, 7_200_300):
+    for seed in seeds(7_200_000, 7_200_300):
         run_stripe_case(seed, 3)
-    for seed in range(7_300_000, 7_300_300):
+    for seed in seeds(7_300_000, 7_300_300):
         run_stripe_case(seed, 8)
-    for seed in range(7_400_000, 7_400_300):
+    for seed in seeds(7_400_000, 7_400_300):
         run_stripe_case(seed, -2)  # one overwritten byte and two streams cut short
 
 
 def test_wide_type_family():
     """Binary / Varchar / Char / TimestampInstant columns, decimals of other precisions and scales."""
-    for seed in range(7_600_000, 7_600_250):
+    for seed in seeds(7_600_000, 7_600_250):
         n, comp, block, batch, cols, streams, _ = F.make_case(seed, False, 1, True)
         res = G.gpu_decode(n, cols, streams, compression=comp, block_size=block, batch_size=batch)
         G.assert_stripe_parity(res, cols, streams, n, batch, compression=comp, block_size=block, what=(seed, comp, block, batch, n))
         res.free()
     # 3309319/4: string lengths whose i64 sum wraps below zero
-    for seed, hits in [(3309319, 4)] + [(s, 1 + s % 4) for s in range(7_700_000, 7_700_300)]:
+    for seed, hits in [(3309319, 4)] + [(s, 1 + s % 4) for s in seeds(7_700_000, 7_700_300)]:
         n, comp, block, batch, cols, streams, _ = F.make_case(seed, True, hits, True)
         res = G.gpu_decode(n, cols, streams, compression=comp, block_size=block, batch_size=batch)
         try:
@@ -106,7 +116,7 @@ def test_failing_stripes_do_not_disturb_their_neighbours():
     """Stripes of one orcgpu_decode_staged call share every launch (one job table, one summary): valid and
     corrupted stripes mixed in one call must each come out as they do alone."""
     ctx = G.ctx()
-    for base in range(7_500_000, 7_500_120, 12):
+    for base in range(7_500_000 + SHIFT, 7_500_120 + SHIFT, 12):
         cases = [F.make_case(base + k, k % 3 == 1, 3) for k in range(12)]
         staged = [ctx.stage(n, streams, cols, compression=comp, block_size=block, batch_size=batch) for n, comp, block, batch, cols, streams, _ in cases]
         results = ctx.decode(staged)
