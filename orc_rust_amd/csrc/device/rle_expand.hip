@@ -720,6 +720,7 @@ __device__ __forceinline__ void expand_entry(RleJob* jobs, const uint32_t* group
   RleJob* j = &jobs[group_job[g]];
   uint32_t lg = g - j->group0;
   if (lg >= j->ngroups) return;
+  if (j->uniform_idx && scalars[j->uniform_idx]) return;  // (one value throughout: rle2_uniform_kernel; nobody reads the job's output)
   PROF_MARK(9);
   if (CODEC == CODEC_BYTE) {
     expand_group<CODEC, 1>(j, blk, scalars, lg, lds[wv], lane PROF_ARG);
@@ -739,6 +740,47 @@ __device__ __forceinline__ void expand_entry(RleJob* jobs, const uint32_t* group
     }
   }
   PROF_END();
+}
+
+// The scale of every value of a Decimal column is the column's scale in every file a writer made (decimal.rs:28-52 still reads it value
+// by value): its SECONDARY stream then is one run over and over -- DELTA, fixed delta 0, 512 values: C1 FF zz 00 -- and a shorter last
+// one (the same with a smaller count, or a SHORT_REPEAT of one byte).  Expanding it writes 4 bytes per value that the varint decoder
+// reads back only to find the scale it was given (lineitem: 1.2 GB each way per step, 0.7 ms of expansion).  One workgroup per such job
+// compares the stream with that pattern and counts its values: a stream that IS the pattern and holds the values the column needs
+// sets the job's flag; anything else leaves the job to the expansion, which stays the authority on every other stream and every error.
+extern "C" __global__ void __launch_bounds__(256) rle2_uniform_kernel(const RleJob* jobs, uint32_t n_jobs, uint64_t* scalars) {
+  if (blockIdx.x >= n_jobs) return;
+  const RleJob& j = jobs[blockIdx.x];
+  if (!j.uniform_idx || j.codec != CODEC_RLE2 || !j.is_signed || j.skip || j.uniform_value >= 64) return;
+  __shared__ uint32_t differs;
+  if (threadIdx.x == 0) differs = 0;
+  __syncthreads();
+  const uint8_t* d = j.data;
+  const uint64_t len = scalars[j.len_idx], needed = scalars[j.needed_idx];
+  const uint32_t zz = j.uniform_value << 1;  // (zigzag of a non-negative value below 64: one varint byte)
+  const uint32_t pat = 0xC1u | 0xFFu << 8 | zz << 16;
+  const uint64_t nw = len / 4;
+  bool bad = false;
+  for (uint64_t i = threadIdx.x; i + 1 < nw; i += 256) bad = bad || ld_u32(d + 4 * i) != pat;
+  if (bad) differs = 1;
+  __syncthreads();
+  if (threadIdx.x == 0 && !differs && len >= 2) {
+    uint64_t total = 0;
+    bool ok = true;
+    if (nw) {
+      const uint32_t w = ld_u32(d + 4 * (nw - 1));
+      // DELTA, width code 0 (fixed delta), any count; base zz, delta 0
+      if ((w & 0xFEu) == 0xC0u && ((w >> 16) & 0xffu) == zz && (w >> 24) == 0) total = 512 * (nw - 1) + ((((w & 1u) << 8) | ((w >> 8) & 0xffu)) + 1u);
+      else ok = false;
+    }
+    const uint32_t rem = (uint32_t)(len & 3);
+    if (rem == 2) {
+      // SHORT_REPEAT of one byte: 00 | width - 1 = 0 | count - 3
+      if ((d[len - 2] & 0xF8u) == 0 && d[len - 1] == zz) total += (d[len - 2] & 7u) + 3u;
+      else ok = false;
+    } else if (rem) ok = false;
+    if (ok && total >= needed) scalars[j.uniform_idx] = 1;
+  }
 }
 
 extern "C" __global__ void __launch_bounds__(256, ORC_EXPAND_WAVES) rle2_expand_kernel(RleJob* jobs, const uint32_t* group_job, RleBlocks blk, const uint64_t* scalars,

@@ -34,6 +34,10 @@ struct RleJob {
   // verified run starts (orcgpu_stream::entries): this job's slice of the call's RleHint table; hint_bad is set by
   // rle_hint_kernel when the entries do not lie on one run chain (they are then ignored)
   uint32_t hint0, n_hints, hint_bad, hint_skip;
+  // a stream that is expected to hold ONE value throughout (the SECONDARY stream of a Decimal column: every value's scale, which every
+  // writer makes the column's): scalars[uniform_idx] is set by rle2_uniform_kernel when the stream's bytes say so -- the expansion then
+  // skips the job and the consumer takes `uniform_value` for every value; 0: no such check
+  uint32_t uniform_idx, uniform_value;
   unsigned long long err;  // min over (first value index of the failing run << 8 | ORC_E_*)
   unsigned long long err_pos;  // min over (stream position of the failing run << 8 | ORC_E_*): its code is the first failure's
 };

@@ -781,7 +781,10 @@ __device__ __forceinline__ __int128 decimal_rescale(__int128 v, uint32_t vs, uin
 // written, is not run.
 __device__ __forceinline__ void varint_decode128_body(const uint8_t* s, const uint64_t* scalars, uint32_t len_idx, uint32_t needed_idx,
                                                                            const unsigned long long* tmask, const uint32_t* trank, __int128* dense,
-                                                                           uint64_t n_upper, unsigned long long* err, const int32_t* scales, uint32_t fixed_scale) {
+                                                                           uint64_t n_upper, unsigned long long* err, const int32_t* scales_, uint32_t fixed_scale,
+                                                                           const uint64_t* uniform) {
+  // (`uniform`: the flag of rle2_uniform_kernel -- every value's scale is the column's: the scales were not expanded)
+  const int32_t* scales = uniform && *uniform ? nullptr : scales_;
   // The values of a workgroup's 2 KiB of stream are one contiguous run of the output: they are gathered in LDS and leave as
   // consecutive 16-byte stores.  (Stored from the thread that decodes them -- its two to four values at a lane stride of 32 to 64
   // bytes, one value per instruction -- every instruction wrote a quarter to a half of each 64-byte line it touched: 2.5 x the

@@ -630,6 +630,7 @@ struct JobPlan {
   uint32_t skip_values = 0;            // of the stream's entry point: decoded in front of the output (RleJob::skip)
   const StagedStream* hint_src = nullptr;  // verified run starts, if the stream has any
   uint32_t chunk0 = 0;
+  uint32_t uniform_idx = 0, uniform_value = 0;  // RleJob::uniform_idx / uniform_value (a Decimal column's scales)
   int stripe = 0, col = 0, role = 0;  // role: stream kind the job decodes
   int final_index = -1;
 };
@@ -665,6 +666,7 @@ struct ColPlan {
   int parent_plan = -1;       // index in Plan::cols of the Struct this column is a field of (only when that one has validity)
   int depth = 0;              // Structs above it
   uint32_t ceil8_idx = 0;     // Struct: scalar holding ceil(non-null rows / 8), the length of its fields' PRESENT streams
+  uint32_t uniform_idx = 0;   // Decimal without nulls: scalar that says "every value's scale is the column's" (rle2_uniform_kernel); 0: none
   uint32_t child_bits = 0;    // ... entered at a row group in mid-byte: the bits of their first byte that belong to the rows before
   bool child_bits_set = false;
   // Union (union.rs:69-136): behind the Union's own plan follow its ARMS, one per child: plans without a column of their own

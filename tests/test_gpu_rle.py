@@ -423,6 +423,41 @@ def test_decimals():
     G.assert_column_parity(res, 0, cols[0], streams2, n, 8192, what="decimal truncated")
 
 
+@pytest.mark.parametrize("compression", ["none", "zstd"])
+def test_decimal_scales_that_are_the_columns_scale_throughout(compression):
+    """A Decimal column without nulls whose SECONDARY stream holds the column's scale and nothing else -- what every writer makes --
+    is decoded without expanding that stream (rle2_uniform_kernel: the stream must BE k runs of 512 and a shorter last one, and hold
+    a value per row).  Row counts around the run length (the last run as a DELTA run, as a SHORT_REPEAT, as one or two literal
+    values: not the pattern -- the expansion takes those), a scale that is NOT the column's, one odd value in the middle, a stream
+    that ends too early: every one of them must come out as the oracle has it."""
+    DECIMAL = 14
+    rng = np.random.default_rng(77)
+
+    def case(n, scales, col_scale=2, cut=None, what=""):
+        vals = [int(x) for x in rng.integers(-10**12, 10**12, n)]
+        sec = gen.rle2(np.asarray(scales, dtype=np.int64), signed=True)
+        if cut is not None:
+            sec = sec[:cut]
+        cols = [col(1, DECIMAL, precision=20, scale=col_scale)]
+        raw = [(1, DATA, gen.varint128(vals)), (1, SECONDARY, sec)]
+        streams = raw if compression == "none" else [(c, k, gen.compress_stream(b, compression, 4096)) for c, k, b in raw]
+        kw = {} if compression == "none" else {"compression": compression, "block_size": 4096}
+        res = G.gpu_decode(n, cols, streams, **kw)
+        G.assert_column_parity(res, 0, cols[0], streams, n, 8192, what=("uniform scales", what, n, compression), **kw)
+
+    for n in (1, 2, 3, 9, 10, 11, 511, 512, 513, 514, 515, 522, 523, 1024, 1025, 20000, 20480):
+        case(n, np.full(n, 2), what="the column's scale")
+    case(20000, np.full(20000, 3), what="another scale throughout")
+    odd = np.full(20000, 2)
+    odd[12345] = 4
+    case(20000, odd, what="one odd value")
+    case(20000, np.full(20000, 2), col_scale=0, what="scale 0 column, scales 2")
+    case(20000, np.full(20000, 0), col_scale=0, what="scale 0 throughout")
+    full = gen.rle2(np.full(20000, 2, dtype=np.int64), signed=True)
+    case(20000, np.full(20000, 2), cut=len(full) - 4, what="a run short")
+    case(20000, np.full(20000, 2), cut=len(full) - 1, what="a byte short")
+
+
 @pytest.mark.parametrize("kind", ["snappy", "lz4", "zlib", "zstd"])
 @pytest.mark.parametrize("block", [64, 4096, 262144])
 def test_compressed_streams(kind, block):
