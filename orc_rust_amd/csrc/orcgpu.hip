@@ -646,6 +646,7 @@ struct PlainStream {
   const StagedStream* src = nullptr;  // (for its verified run starts)
   uint32_t chunk0 = 0;           // compressed: index of the stream's first chunk in the call's chunk table
   bool exists = false;
+  bool in_result = false;        // decompressed into the column's value buffer (DecompStream::result_index): no plain copy in the workspace
 };
 
 constexpr int ORCGPU_RETRY_LARGER_SLOTS = 1000;  // internal: decode_lane asks for a second run (never leaves the library)
@@ -655,6 +656,10 @@ struct DecompStream {
   const StagedStream* st;
   uint64_t scratch_off;
   uint32_t len_idx, err_idx;
+  // the DATA stream of a direct string column IS the column's Arrow value buffer: its chunks are decompressed straight into the
+  // result arena (results[result_index], at result_off) instead of a slot of the workspace that a finisher then copies there
+  int result_index = -1;
+  uint64_t result_off = 0;
 };
 
 struct ColPlan {
