@@ -628,8 +628,10 @@ __device__ __forceinline__ int utf8_lead_len(uint8_t c) {
 }
 // (16 bytes per thread: a vector without a byte >= 0x80 -- ASCII text, the common case -- is done with its one load)
 __device__ __forceinline__ void utf8_validate_byte(const uint8_t* s, uint64_t i, uint64_t n, unsigned long long* err);
+// `nonascii` (may be null): set when the text holds a byte of 0x80 or more -- text without one has no row offset inside a character,
+// utf8_boundaries_body then has nothing to look for (a read of one byte per row at 75 M places of lineitem's l_comment otherwise)
 __device__ __forceinline__ void utf8_validate_body(const uint8_t* s, const uint64_t* scalars, uint32_t n_idx, uint32_t len_idx,
-                                                                        unsigned long long* err) {
+                                                                        unsigned long long* err, uint64_t* nonascii) {
   const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
   uint64_t n = scalars[n_idx];
   if (n > scalars[len_idx]) n = scalars[len_idx];  // only bytes the stream really holds (a cut stream leaves stale ones behind)
@@ -641,12 +643,15 @@ __device__ __forceinline__ void utf8_validate_body(const uint8_t* s, const uint6
   }
   const uint64_t i1 = i0 + 16 < n ? i0 + 16 : n;
   for (uint64_t i = i0; i < i1; i++)
-    if (s[i] >= 0x80) utf8_validate_byte(s, i, n, err);
+    if (s[i] >= 0x80) {
+      if (nonascii) *nonascii = 1;
+      utf8_validate_byte(s, i, n, err);
+    }
 }
 // A direct string column's DATA stream is its Arrow value buffer: copied there AND checked in one pass (16 bytes per thread, the
 // vector the copy has in its registers: ASCII text is done with it; round 4 read the 1.9 GB of lineitem's l_comment a second time)
 __device__ __forceinline__ void copy_validate_body(const uint8_t* src, uint8_t* dst, uint64_t n_copy, const uint64_t* scalars, uint32_t n_idx, uint32_t len_idx,
-                                                   unsigned long long* err) {
+                                                   unsigned long long* err, uint64_t* nonascii) {
   const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
   if (i0 >= n_copy) return;
   uint64_t n = scalars[n_idx];
@@ -661,7 +666,10 @@ __device__ __forceinline__ void copy_validate_body(const uint8_t* src, uint8_t* 
   }
   const uint64_t i1 = i0 + 16 < n ? i0 + 16 : n;
   for (uint64_t i = i0; i < i1; i++)
-    if (src[i] >= 0x80) utf8_validate_byte(src, i, n, err);
+    if (src[i] >= 0x80) {
+      if (nonascii) *nonascii = 1;
+      utf8_validate_byte(src, i, n, err);
+    }
 }
 __device__ __forceinline__ void utf8_validate_byte(const uint8_t* s, uint64_t i, uint64_t n, unsigned long long* err) {
   const uint8_t c = s[i];
@@ -705,9 +713,10 @@ __device__ __forceinline__ void utf8_validate_byte(const uint8_t* s, uint64_t i,
 __device__ __forceinline__ void utf8_boundaries_body(const uint8_t* s, const int32_t* offsets, const unsigned long long* charbase,
                                                                           const unsigned long long* chartot, uint64_t n_rows, uint32_t batch,
                                                                           const uint64_t* scalars, uint32_t n_idx, uint32_t len_idx,
-                                                                          unsigned long long* err) {
+                                                                          unsigned long long* err, const uint64_t* nonascii) {
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_rows) return;
+  if (nonascii && !*nonascii) return;  // (pure ASCII: no offset can lie inside a character -- the validation pass has seen every byte)
   const uint64_t b = i / batch;
   const uint64_t base = charbase ? charbase[b] : 0;
   const uint64_t p = base + (uint64_t)(uint32_t)offsets[b * ((uint64_t)batch + 1) + (i - b * batch)];

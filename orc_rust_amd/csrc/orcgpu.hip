@@ -671,6 +671,7 @@ struct ColPlan {
   int parent_plan = -1;       // index in Plan::cols of the Struct this column is a field of (only when that one has validity)
   int depth = 0;              // Structs above it
   uint32_t ceil8_idx = 0;     // Struct: scalar holding ceil(non-null rows / 8), the length of its fields' PRESENT streams
+  uint32_t nonascii_idx = 0;  // direct Utf8: scalar the validation pass sets when the text holds a byte >= 0x80 (else no offset check is needed)
   uint32_t uniform_idx = 0;   // Decimal without nulls: scalar that says "every value's scale is the column's" (rle2_uniform_kernel); 0: none
   uint32_t child_bits = 0;    // ... entered at a row group in mid-byte: the bits of their first byte that belong to the rows before
   bool child_bits_set = false;
