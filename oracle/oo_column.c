@@ -293,6 +293,14 @@ static int decode_dense(oo_column* c, uint8_t* dense, size_t k) {
         }
       free(v);
       free(sc);
+      /* array_decoder/decimal.rs:96-100: the batch then goes through with_precision_and_scale, which arrow-rs refuses (ArrowError) for a
+       * precision outside 1..=38, a scale above 38 or -- positive -- above the precision; the reference takes the footer's numbers
+       * `as u8` / `as i8` (decimal.rs:59-60).  A stream failure of the batch comes first. */
+      if (!st) {
+        const uint32_t pr = c->d.precision & 0xffu;
+        const int sc8 = (int8_t)c->d.scale;
+        if (pr == 0 || pr > 38 || sc8 > 38 || (sc8 > 0 && (uint32_t)sc8 > pr)) st = OO_ARROW;
+      }
       return st;
     }
     case OO_T_TIMESTAMP:

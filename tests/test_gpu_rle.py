@@ -423,6 +423,27 @@ def test_decimals():
     G.assert_column_parity(res, 0, cols[0], streams2, n, 8192, what="decimal truncated")
 
 
+@pytest.mark.parametrize("precision, scale", [(0, 0), (39, 2), (5, 6), (38, 39), (256, 0), (266, 2), (10, 255)])
+def test_decimal_types_arrow_refuses(precision, scale):
+    """array_decoder/decimal.rs:96-100: a precision outside 1..=38 (taken `as u8`), a scale above 38 or above the precision is an
+    ArrowError of the first batch -- behind a stream failure of that batch --; with nulls and without (the oracle restates it,
+    tests/test_oracle_kat.py::test_decimal_types_arrow_refuses)."""
+    DECIMAL = 14
+    n = 20000
+    rng = np.random.default_rng(precision * 100 + scale)
+    for nulls in (False, True):
+        present = (rng.random(n) >= 0.2).astype(np.uint8) if nulls else np.ones(n, dtype=np.uint8)
+        k = int(present.sum())
+        vals = [int(x) for x in rng.integers(-10**9, 10**9, k)]
+        cols = [col(1, DECIMAL, precision=precision, scale=scale)]
+        streams = ([(1, PRESENT, gen.boolean(present))] if nulls else []) + [(1, DATA, gen.varint128(vals)), (1, SECONDARY, gen.rle2(np.full(k, scale & 0x7f, dtype=np.int64), signed=True))]
+        res = G.gpu_decode(n, cols, streams)
+        G.assert_column_parity(res, 0, cols[0], streams, n, 8192, what=("decimal type", precision, scale, nulls))
+        cut = [(c, kd, b if kd != DATA else b[: len(b) // 3]) for c, kd, b in streams]
+        res = G.gpu_decode(n, cols, cut)
+        G.assert_column_parity(res, 0, cols[0], cut, n, 8192, what=("decimal type, DATA cut", precision, scale, nulls))
+
+
 @pytest.mark.parametrize("compression", ["none", "zstd"])
 def test_decimal_scales_that_are_the_columns_scale_throughout(compression):
     """A Decimal column without nulls whose SECONDARY stream holds the column's scale and nothing else -- what every writer makes --

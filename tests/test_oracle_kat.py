@@ -173,6 +173,23 @@ def test_timestamp_rules():  # encoding/timestamp.rs:121-192
     assert O.decode_timestamp(base, 1 << 40, 0, unit=0) == (O.OK, base + (1 << 40))
 
 
+def test_decimal_types_arrow_refuses():  # array_decoder/decimal.rs:96-100 (with_precision_and_scale), :59-60 (`as u8` / `as i8`)
+    """Every batch of a Decimal column is given its precision and scale by arrow-rs, which refuses a precision outside 1..=38, a scale
+    above 38 and a positive scale above the precision: an ArrowError of the batch, behind whatever its streams fail at."""
+    import numpy as np
+    from orc_rust_amd import gen
+    vals = [1, -2, 300]
+    DATA, SECONDARY = 1, 5  # Stream.Kind
+    streams = {DATA: bytes(gen.varint128(vals)), SECONDARY: bytes(gen.rle2(np.full(3, 2, dtype=np.int64), signed=True))}
+    for precision, scale, want in ((10, 2, O.OK), (38, 38, O.OK), (1, 0, O.OK), (0, 0, O.ARROW), (39, 2, O.ARROW), (5, 6, O.ARROW), (38, 39, O.ARROW),
+                                   (256 + 10, 2, O.OK), (256, 0, O.ARROW), (10, 256 + 2, O.OK), (10, 255, O.OK)):  # (255 as i8 = -1: negative scales pass)
+        c = O.Column(14, 2, streams, precision=precision, scale=scale)
+        assert c.next_batch(3)["status"] == want, (precision, scale)
+    # a stream that fails in the batch comes first
+    c = O.Column(14, 2, {DATA: bytes(gen.varint128([10**20]))[:1], SECONDARY: streams[SECONDARY]}, precision=0, scale=0)
+    assert c.next_batch(3)["status"] == O.IO_ERROR
+
+
 def test_decimal_scale_repair():  # array_decoder/decimal.rs:138-166
     assert O.fix_scale(12345, 2, 2) == 12345
     assert O.fix_scale(12345, 2, 4) == 123
