@@ -156,6 +156,10 @@ class Map(List):
         present, offsets, total = self._offsets(n, parent)
         keys = self.kids[0].next_batch(total, None)
         items = self.kids[1].next_batch(total, None)
+        # map.rs:90-99: keys and values become a StructArray whose `keys` field is not nullable -- arrow-rs refuses a key column with a
+        # null in it ("Found unmasked nulls for non-nullable StructArray field": ArrowError)
+        if keys.null_count:
+            raise OracleError(O.ARROW, "null keys")
         return pa.MapArray.from_arrays(offsets, keys, items, mask=_mask(present))
 
 
